@@ -1,0 +1,236 @@
+"""ctypes driver of the REAL reference Fortran (oracle/_ref/libsos_ref.so).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this; the product path (radiativetransfer-sos_amd/) never does.
+
+libsos_ref.so is built by oracle/Makefile from the unmodified sources under /root/reference/src
+with amdflang (flang conventions: lower-case symbol + '_', every scalar by reference, CHARACTER*n
+as a blank-padded buffer with one size_t length per character argument appended after all declared
+arguments).  The reference keeps ~19 MB of work arrays on the stack (SOS_OS.F:447-548), so every
+call runs in a thread with a 1 GiB stack instead of requiring `ulimit -s unlimited`.
+
+The reference is not re-entrant (fixed Fortran units 10/12, SOS_OS.F:665-672): calls are serialised
+by a lock and each one works in its own temporary directory.
+"""
+import ctypes as C
+import os
+import re
+import shutil
+import tempfile
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(HERE, "_ref", "libsos_ref.so")
+
+# inc/SOS.h dimensions (SOS.h:202,471,480,488,496,59)
+NT_MAX = 600
+NBMU_MAX = 80
+NB_MAX = 200
+NS_MAX = 136
+NM_MAX = 336
+LENFIC2 = 500
+
+_lock = threading.Lock()
+_lib = None
+
+
+def available():
+    return os.path.exists(REF_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(REF_SO)
+    return _lib
+
+
+def _big_stack_call(fn, *args):
+    """Run fn(*args) in a thread with a 1 GiB stack (flang puts the big locals on the stack)."""
+    out = {}
+
+    def run():
+        try:
+            out["r"] = fn(*args)
+        except BaseException as e:  # pragma: no cover
+            out["e"] = e
+
+    with _lock:
+        old = threading.stack_size(1 << 30)
+        try:
+            t = threading.Thread(target=run)
+            t.start()
+            t.join()
+        finally:
+            threading.stack_size(old)
+    if "e" in out:
+        raise out["e"]
+    return out["r"]
+
+
+def _fstr(s, n=LENFIC2):
+    b = s.encode()
+    assert len(b) <= n
+    return C.create_string_buffer(b + b" " * (n - len(b)), n)
+
+
+def _dir_array(pos, sign):
+    """Build X(-80:80) from X(1..N); X(-j) = sign*X(j); X(0)=0."""
+    a = np.zeros(2 * NBMU_MAX + 1)
+    n = len(pos)
+    a[NBMU_MAX + 1:NBMU_MAX + 1 + n] = pos
+    a[NBMU_MAX - n:NBMU_MAX] = sign * np.asarray(pos)[::-1]
+    return a
+
+
+def _lev_array(x):
+    a = np.zeros(NT_MAX + 1)
+    a[:len(x)] = x
+    return a
+
+
+def _coef_array(x):
+    a = np.zeros(NB_MAX + 1)
+    a[:len(x)] = x
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def read_fortran_records(path, dtype="<f8"):
+    """Sequential unformatted file -> list of numpy arrays (4-byte LE record markers)."""
+    recs = []
+    with open(path, "rb") as f:
+        data = f.read()
+    off = 0
+    while off < len(data):
+        n = int(np.frombuffer(data, "<i4", 1, off)[0])
+        recs.append(np.frombuffer(data, dtype, n // np.dtype(dtype).itemsize, off + 4).copy())
+        off += 8 + n
+    return recs
+
+
+def write_surface_file(path, rmat):
+    """rmat: float32 [F][9][N][N] with rmat[s][ab][j][i] = R_ab(I=i+1,J=j+1) (i.e. the file order
+    ((R(I,J),I=1,N),J=1,N), SOS_OS.F:916-925) -> Fortran sequential unformatted file."""
+    rmat = np.ascontiguousarray(rmat, dtype="<f4")
+    with open(path, "wb") as f:
+        for s in range(rmat.shape[0]):
+            payload = rmat[s].tobytes()
+            m = np.array([len(payload)], "<i4").tobytes()
+            f.write(m + payload + m)
+
+
+def sos_os(rmu, ga, os_nb, h, xdel, ydel, alpha, beta, gamma, zeta, *, n0, tetas=0.0, ro=0.0,
+           imat_surf=0, ifresnel=0, ind_surf=1.34, zprof=None, ron=float(np.float32(0.0279)), zout=-1.0,
+           igmax=100, iborm=None, ipolar=1, rsurf=None, want_log=True):
+    """Call the reference SOS_OS (SOS_OS.F:303).  rmu/ga: positive directions 1..N (N=NBMU).
+    h/xdel/ydel: levels 0..NT.  Returns dict(records[F,3,2N+1] in (I,Q,U) order, emoins, eplus, ier,
+    ig_counts[F], log)."""
+    n = len(rmu)
+    nt = len(h) - 1
+    if iborm is None:
+        iborm = os_nb
+    if zprof is None:
+        zprof = np.linspace(120.0, 0.0, nt + 1)
+    tmp = tempfile.mkdtemp(prefix="sosref_")
+    try:
+        ficos = os.path.join(tmp, "FICOS")
+        ficsurf = os.path.join(tmp, "SURF")
+        if imat_surf == 1:
+            write_surface_file(ficsurf, rsurf)
+        RMU = _dir_array(rmu, -1.0)
+        GA = _dir_array(ga, 1.0)
+        H, XD, YD, ZP = _lev_array(h), _lev_array(xdel), _lev_array(ydel), _lev_array(zprof)
+        AL, BE, GM, ZE = (_coef_array(x) for x in (alpha, beta, gamma, zeta))
+        i4 = lambda v: C.byref(C.c_int32(v))
+        f8 = lambda v: C.byref(C.c_double(v))
+        emoins, eplus, ier = C.c_double(0), C.c_double(0), C.c_int32(0)
+        idlog = 21  # SOS_OS closes unit 21 on exit (SOS_OS.F:1661), which flushes the log
+        cwd = os.getcwd()
+
+        def call():
+            os.chdir(tmp)
+            try:
+                lib().sos_os_(i4(n), _p(RMU), _p(GA), i4(os_nb), i4(nt), _fstr(ficsurf), _fstr(ficos),
+                              i4(n0), f8(tetas), f8(ro), i4(imat_surf), i4(ifresnel), f8(ind_surf),
+                              _p(H), _p(XD), _p(YD), _p(ZP), f8(ron), _p(AL), _p(BE), _p(GM), _p(ZE),
+                              f8(zout), i4(igmax), i4(iborm), i4(ipolar), i4(1 if want_log else 0), i4(idlog),
+                              C.byref(emoins), C.byref(eplus), C.byref(ier),
+                              C.c_size_t(LENFIC2), C.c_size_t(LENFIC2))
+            finally:
+                os.chdir(cwd)
+
+        _big_stack_call(call)
+        recs = read_fortran_records(ficos) if os.path.exists(ficos) else []
+        w = 2 * n + 1
+        out = np.zeros((len(recs), 3, w))
+        for s, r in enumerate(recs):
+            q, u, i = r[:w], r[w:2 * w], r[2 * w:3 * w]
+            out[s, 0], out[s, 1], out[s, 2] = i, q, u
+        out[:, :, n] = 0.0  # index 0 is never initialised by the reference (SOS_OS.F:337-358)
+        log = ""
+        ig_counts = []
+        logf = os.path.join(tmp, "fort.%d" % idlog)
+        if os.path.exists(logf):
+            log = open(logf, errors="replace").read()
+            ig_counts = parse_ig_counts(log, igmax)
+        return dict(records=out, emoins=emoins.value, eplus=eplus.value, ier=ier.value,
+                    ig_counts=np.array(ig_counts, dtype=np.int32), log=log)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+_RE_IS = re.compile(r"Fourier series expansion order: IS =\s+(\d+)")
+_RE_GEO = re.compile(r"Convergence in geometric series from IG =\s+(\d+)")
+_RE_END = re.compile(r"for IG =\s+(\d+)")
+_RE_MAX = re.compile(r"the maximal order : IGMAX")
+
+
+def parse_ig_counts(log, igmax):
+    """Last scattering order IG computed for each Fourier order, from the TRACE log messages
+    (SOS_OS.F:1306-1309, 1374-1379, 1393-1398, 1410-1414)."""
+    counts = []
+    cur = None
+    for line in log.splitlines():
+        m = _RE_IS.search(line)
+        if m:
+            cur = int(m.group(1))
+            counts.append(-1)
+            continue
+        if cur is None:
+            continue
+        m = _RE_GEO.search(line) or _RE_END.search(line)
+        if m and counts[-1] < 0:
+            counts[-1] = int(m.group(1))
+        elif _RE_MAX.search(line) and counts[-1] < 0:
+            counts[-1] = igmax
+    return counts
+
+
+def sos_noyaux(is_, rmu0, rmu, os_nb, alpha, beta, gamma, zeta):
+    """Reference SOS_NOYAUX (SOS_OS.F:1857).  rmu0 = RMU(0) = -mus.  Returns dict of (2N+1,2N+1) arrays
+    indexed [j+N][k+N] (i.e. X(J,K)) plus XPL/XRL/XTL (2N+1)."""
+    n = len(rmu)
+    RMU = _dir_array(rmu, -1.0)
+    RMU[NBMU_MAX] = rmu0
+    AL, BE, GM, ZE = (_coef_array(x) for x in (alpha, beta, gamma, zeta))
+    w = 2 * NBMU_MAX + 1
+    vec = [np.zeros(w) for _ in range(3)]
+    mats = [np.zeros((w, w), order="F") for _ in range(6)]
+    i4 = lambda v: C.byref(C.c_int32(v))
+
+    def call():
+        lib().sos_noyaux_(i4(is_), i4(n), _p(RMU), i4(os_nb), _p(AL), _p(BE), _p(GM), _p(ZE),
+                          *[_p(v) for v in vec], *[_p(m) for m in mats])
+
+    _big_stack_call(call)
+    sl = slice(NBMU_MAX - n, NBMU_MAX + n + 1)
+    names = ["BP", "GR", "GT", "ARR", "ART", "ATT"]
+    out = {k: m[sl, sl].copy() for k, m in zip(names, mats)}
+    out.update({k: v[sl].copy() for k, v in zip(["XPL", "XRL", "XTL"], vec)})
+    return out
