@@ -1,0 +1,130 @@
+/* include/sosgpu.h -- C ABI of libsosgpu.so, the MI355X (gfx950) drop-in for the SOS-ABS hot path.
+ *
+ * Plain C: pointers + sizes, int status (0 ok, negative = error, see sosgpu_strerror).  No torch
+ * types, no Fortran hidden lengths, no files.  All `d_` pointers are DEVICE (HBM) addresses owned by
+ * the caller (the Python host allocates them with torch); `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  Calls are asynchronous on `stream` unless stated.
+ *
+ * Each entry point replaces one routine of the reference per-wavelength pipeline that
+ * binding/run_sos.py reaches through sos.sos_proc (binding/run_sos.py:640, SOS_PROC.F:415):
+ *
+ *   sosgpu_noyaux      <- SOS_NOYAUX              src/SOS_OS.F:1857   (phase-matrix Fourier kernels,
+ *                                                                     hoisted out of the bin loop)
+ *   sosgpu_os_solve    <- SOS_OS (+ leaves)       src/SOS_OS.F:303    (one call = a batch of CKD bins,
+ *                                                                     i.e. the loop SOS_PROC.F:3459-3594)
+ *   sosgpu_aggregate   <- SOS_AGGREGATE           src/SOS_AGGREGATE.F:172
+ *   sosgpu_glitter     <- SOS_GLITTER (+SOS_GSF, SOS_MAT_FRESNEL, SOS_MAT_REFLEXION, SOS_MISE_FORMAT)
+ *                                                 src/SOS_GLITTER.F:229, src/SOS_SURFACE.F:1235,1708,2307
+ *   sosgpu_trphi       <- SOS_TRPHI               src/SOS_TRPHI.F:749
+ *
+ * Index conventions (identical to oracle/sos_oracle.h): N = NBMU positive directions, mu[0..N-1] =
+ * RMU(1..N) descending; direction jj in -N..N lives at offset jj+N of width W = 2N+1 (slot jj=0 is
+ * unused and written as 0); Fourier records rec[s][c][W], c = 0:I 1:Q 2:U; level 0 = TOA.
+ */
+#ifndef SOSGPU_H
+#define SOSGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOSGPU_OK            0
+#define SOSGPU_E_ARG        -1   /* bad argument / inconsistent sizes (reference IER=-1) */
+#define SOSGPU_E_HIP        -2   /* HIP runtime error (sosgpu_last_hip_error) */
+#define SOSGPU_E_UNSUPPORTED -3  /* size outside the compiled kernel variants */
+#define SOSGPU_E_NODEVICE   -4   /* no gfx950 device visible */
+
+/* Per-wavelength description (everything SOS_OS receives that does not depend on the CKD bin). */
+typedef struct sosgpu_wave {
+    int32_t n;          /* NBMU: Gauss + sun (+ user) positive directions, <= 80 (SOS.h:471) */
+    int32_t os_nb;      /* max Legendre order of the phase-matrix expansion, <= 200 (SOS.h:480) */
+    int32_t n0;         /* 1-based index of the solar direction in mu[] (N0 of SOS_OS); mus = mu[n0-1] */
+    int32_t imat_surf;  /* 1: BRDF/BPDF matrices given in d_rsurf (SOS_OS.F:912-925) */
+    int32_t ifresnel;   /* 1: flat-sea Fresnel reflection (SOS_OS.F:817,1010,1225) */
+    int32_t ipolar;     /* 0: no polarisation (SOS_OS.F:689-699, 928-941), 1: normal */
+    int32_t igmax;      /* max scattering order (CTE_DEFAULT_IGMAX = 100) */
+    int32_t reserved;
+    double  ro;         /* Lambertian albedo */
+    double  ind_surf;   /* refractive index (Fresnel) */
+    double  ron;        /* molecular depolarisation factor (CTE_MDF) */
+} sosgpu_wave;
+
+/* Opaque per-wavelength context living on one device. */
+typedef struct sosgpu_ctx sosgpu_ctx;
+
+const char *sosgpu_strerror(int code);
+int  sosgpu_last_hip_error(void);
+/* Number of visible gfx950 devices, or negative error. */
+int  sosgpu_device_count(void);
+const char *sosgpu_version(void);
+
+/* Create / destroy a context on `device`.  Host arrays are copied: mu[n], ga[n] (Gauss weights, 0 for
+ * the sun/user angles), alpha/beta/gamma/zeta[os_nb+1].  iborm_max = highest Fourier order any bin of
+ * this wavelength may need (OS_NB, or 2 for a purely molecular atmosphere, SOS.F:549-550). */
+int  sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv, const double *mu, const double *ga,
+                   const double *alpha, const double *beta, const double *gamma, const double *zeta,
+                   int iborm_max);
+int  sosgpu_destroy(sosgpu_ctx *cx);
+
+/* Surface reflection matrices for imat_surf=1: REAL*4, reference FICSURF record order
+ * d_rsurf[s][ab][(J-1)*N+(I-1)] = R_ab(I,J), s = 0..iborm_max (SOS_OS.F:916-925).  Device pointer,
+ * borrowed (must stay valid until the last solve). */
+int  sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf);
+
+/* Replaces SOS_NOYAUX (SOS_OS.F:1857-2158) for every Fourier order 0..iborm_max at once; must be called
+ * once per context before sosgpu_os_solve.  Fills the context's packed source operators. */
+int  sosgpu_noyaux(sosgpu_ctx *cx, void *stream);
+/* Debug/parity accessor: copies the six kernels of order `is` to host as the reference lays them
+ * out, X[(j+N)*W + (k+N)] = X(J,K), in the order BP,GR,GT,ARR,ART,ATT, then XPL,XRL,XTL (W each).
+ * Synchronous.  out must hold 6*W*W + 3*W doubles. */
+int  sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out);
+
+/* Replaces the per-bin SOS_OS calls of the CKD loop (SOS_PROC.F:3459-3594 -> SOS.F:554 -> SOS_OS.F:303).
+ *  nb          number of bins in this batch
+ *  lp          padded level count (row stride of d_prof), >= max(nt)+1
+ *  d_nt[nb]    NT of each bin (int32)
+ *  d_iborm[nb] IBORM of each bin (int32; SOS.F:549-550), <= iborm_max
+ *  d_prof[nb][3][lp]   H, XDEL, YDEL after the truncation rescale of SOS.F:523-543
+ *  d_jout[nb]  output level pair for ZOUT != -1: levels jout-1 and jout bracket ZOUT (SOS_OS.F:1514-1520);
+ *              0 = standard output (ZOUT = -1: TOA up, ground down).  May be NULL (= all 0).
+ *  d_zz[nb]    interpolation weight ZZ (SOS_OS.F:1520); ignored when jout = 0.  May be NULL.
+ * outputs
+ *  d_rec[nb][iborm_max+1][3][W]  Fourier records (orders not run are zero)
+ *  d_norders[nb]                 number of Fourier orders run (int32)
+ *  d_iglast[nb][iborm_max+1]     last scattering order computed per Fourier order (int32)
+ *  d_flux[nb][2]                 EMOINS, EPLUS (SOS_OS.F:1447-1456)
+ */
+int  sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const int32_t *d_iborm,
+                     const double *d_prof, const int32_t *d_jout, const double *d_zz,
+                     double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream);
+
+/* Replaces SOS_AGGREGATE (SOS_AGGREGATE.F:372-488) for nseg independent wavelengths/bands at once:
+ * segment g covers bins seg[g]..seg[g+1]-1 of d_rec.
+ *  d_scal[nb][4]  per-bin scalars: TDIFMUS, TTOT_TRONC, TTOT_VRAI, TAUOUT
+ *  d_out_rec[nseg][iborm_max+1][3][W] = sum_b aik[b] * rec[b]
+ *  d_out_scal[nseg][8] = sum aik*{TDIFMUS, EMOINS, EPLUS}, sum aik*exp(-{TTOT_TRONC,TTOT_VRAI,TAUOUT}),
+ *                         sum aik, max norders     (the -ln of the three transmissions is applied by
+ *                         sosgpu_aggregate_finish after the cross-GPU reduce)
+ */
+int  sosgpu_aggregate(sosgpu_ctx *cx, int nseg, const int32_t *d_seg, const double *d_aik,
+                      const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
+                      double *d_out_rec, double *d_out_scal, void *stream);
+
+/* Scratch requirements (bytes) of the context on its device, for memory planning. */
+size_t sosgpu_ctx_bytes(const sosgpu_ctx *cx);
+
+/* Algorithmic flop count of the last sosgpu_os_solve (per (bin, order, scattering
+ * order >= 2) step 2*(6N)^2*(NT+1) [+ the Rayleigh operator for s<=2] + 12*6N*NT), computed on the
+ * host from d_nt/d_norders/d_iglast after a synchronise.  Used by bench.py for roofline.achieved. */
+int  sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, const int32_t *d_norders,
+                     const int32_t *d_iglast, double *flops_out);
+
+/* Time (ms) of the last sosgpu_os_solve kernel, measured with HIP events on its own stream.
+ * Synchronises that stream. */
+int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+"""ctypes binding of libsosgpu.so (C ABI declared in include/sosgpu.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded this module
+raises at first use, loudly.  Build it with `python -m <pkg>.build` / __graft_entry__.build().
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libsosgpu.so")
+
+# every symbol include/sosgpu.h declares (checked by tests/test_cabi.py)
+EXPORTS = [
+    "sosgpu_strerror", "sosgpu_last_hip_error", "sosgpu_device_count", "sosgpu_version",
+    "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_noyaux",
+    "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
+    "sosgpu_os_flops", "sosgpu_last_solve_ms",
+]
+
+
+class SosgpuError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().sosgpu_strerror(code).decode()
+        hip = lib().sosgpu_last_hip_error()
+        super().__init__("%s failed: %s (code %d, hip error %d)" % (where, msg, code, hip))
+
+
+class Wave(C.Structure):
+    """struct sosgpu_wave"""
+    _fields_ = [("n", C.c_int32), ("os_nb", C.c_int32), ("n0", C.c_int32), ("imat_surf", C.c_int32),
+                ("ifresnel", C.c_int32), ("ipolar", C.c_int32), ("igmax", C.c_int32), ("reserved", C.c_int32),
+                ("ro", C.c_double), ("ind_surf", C.c_double), ("ron", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "libsosgpu.so not found at %s: the HIP extension is required (no CPU fallback). "
+                "Run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950)." % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+        L.sosgpu_strerror.restype = C.c_char_p
+        L.sosgpu_strerror.argtypes = [i32]
+        L.sosgpu_version.restype = C.c_char_p
+        L.sosgpu_last_hip_error.restype = i32
+        L.sosgpu_device_count.restype = i32
+        L.sosgpu_create.restype = i32
+        L.sosgpu_create.argtypes = [C.POINTER(vp), i32, C.POINTER(Wave), vp, vp, vp, vp, vp, vp, i32]
+        L.sosgpu_destroy.restype = i32
+        L.sosgpu_destroy.argtypes = [vp]
+        L.sosgpu_set_surface_matrices.restype = i32
+        L.sosgpu_set_surface_matrices.argtypes = [vp, vp]
+        L.sosgpu_noyaux.restype = i32
+        L.sosgpu_noyaux.argtypes = [vp, vp]
+        L.sosgpu_noyaux_fetch.restype = i32
+        L.sosgpu_noyaux_fetch.argtypes = [vp, i32, vp]
+        L.sosgpu_os_solve.restype = i32
+        L.sosgpu_os_solve.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_aggregate.restype = i32
+        L.sosgpu_aggregate.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_ctx_bytes.restype = C.c_size_t
+        L.sosgpu_ctx_bytes.argtypes = [vp]
+        L.sosgpu_os_flops.restype = i32
+        L.sosgpu_os_flops.argtypes = [vp, i32, vp, vp, vp, C.POINTER(dbl)]
+        L.sosgpu_last_solve_ms.restype = i32
+        L.sosgpu_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def check(code, where):
+    if code != 0:
+        raise SosgpuError(code, where)

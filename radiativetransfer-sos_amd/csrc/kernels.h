@@ -1,0 +1,15 @@
+// csrc/kernels.h -- host-side launchers of the gfx950 kernels (internal to libsosgpu.so).
+#pragma once
+#include "sos_common.h"
+
+void launch_noyaux(const SosDev &cx, hipStream_t st);
+void launch_noyaux_fetch(const SosDev &cx, int s, double *d_out, hipStream_t st);
+
+// Fused successive-orders solver.  Returns 0, or SOSGPU_E_UNSUPPORTED when (N, max NT) has no variant.
+int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st);
+// LDS bytes / row-tiles-per-wave the solver would use (for planning and tests); <0 if unsupported.
+int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes);
+
+void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const double *d_aik,
+                      const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
+                      double *d_out_rec, double *d_out_scal, hipStream_t st);

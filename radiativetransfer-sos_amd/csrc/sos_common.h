@@ -1,0 +1,49 @@
+// csrc/sos_common.h -- shared device/host structures of libsosgpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Row ordering of the 6N-long Stokes/direction state vector used by every kernel:
+//   row r = c*2N + d,  c = 0:I 1:Q 2:U,  d < N: up-going direction k = d+1 (mu_k > 0)
+//                                        d >= N: down-going direction k = -(d-N+1)
+// The reference keeps three fields X(0:NT,-N:N) (SOS_OS.F:447-449); this is the same data with the
+// unused jj = 0 column dropped.
+//
+// Packed operator layout (A operand of v_mfma_f64_16x16x4_f64, one f64 per lane):
+//   mp[((rt*KS2 + m)*64 + lane)*2 + e] = M[rt*16 + (lane&15)][8m + 2*(lane>>4) + e]
+// i.e. a wave reads 1 KiB contiguous per pair of k-steps (global_load_dwordx4 per lane) and MFMA k-step
+// (m,e) contracts the K indices {8m + 2q + e : q = 0..3}; the B operand is read from LDS with the same
+// K permutation (one ds_read_b128 per lane per pair of k-steps).
+
+struct SosDev {                 // per-wavelength device context, passed by value to the kernels
+    int n, w, r6;               // N, 2N+1, 6N
+    int kp, ks2, rtp;           // padded K (multiple of 8), kp/8, padded row tiles (4*RTW)
+    int os_nb, smax;            // OS_NB, iborm_max
+    int n0, imat_surf, ifresnel, igmax, ipolar;
+    double mus;                 // cos(solar zenith) = mu[n0-1]; the reference's TAB = -mus
+    double ro;
+    double beta2, gamma2, alpha2;   // molecular coefficients (SOS_OS.F:678-684), polarisation cut applied
+    double f11sun, f12sun;      // Fresnel matrix at the solar incidence (SOS_OS.F:1757-1773, J=0)
+    double thr_cv, thr_sum, thr_val, thr_sf;   // SOS.h:389-400
+    const double *mu, *ga;      // [N]
+    const double *coef;         // [4][os_nb+1] alpha,beta,gamma,zeta (polarisation cut applied)
+    const double *fres;         // [3][N] F11,F12,F33 at mu_k (SOS_OS.F:1753-1780)
+    double *prt;                // [smax+1][3][os_nb+1][W]  P,R,T generalised spherical functions
+    double *mp_aer;             // [smax+1][rtp*ks2*128]
+    double *mp_ray;             // [3][rtp*ks2*128]
+    double *sv;                 // [smax+1][4][kp]: order-1 vectors aer, ray, fresnel-aer, fresnel-ray
+    const float *rsurf;         // [smax+1][9][N][N] or null
+};
+
+struct SosBins {
+    int nb, lp;
+    const int32_t *nt, *iborm, *jout;
+    const double *prof, *zz;
+    double *rec, *flux;
+    int32_t *norders, *iglast;
+};
+
+static inline int sos_round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,459 @@
+// csrc/sos_os.hip -- fused successive-orders-of-scattering solver for a batch of CKD bins (gfx950).
+//
+// Replaces, for every bin of a wavelength at once, the reference call chain
+//   SOS_PROC.F:3459-3594 (bin loop) -> SOS.F:554 -> SOS_OS (src/SOS_OS.F:303-1674)
+// with its leaves SOS_FSOURCE_ORDRE1 (:2431), SOS_FSOURCE_ORDREIG (:2663), SOS_INTEGR_EPOPT (:2222),
+// SOS_FSOURCE_DIFF_FRESNEL1 (:3106), the stop tests (:3377,:3497,:3585,:3709) and SOS_AJOUT_QUEUE (:3871).
+//
+// MI355X mapping (one 256-thread workgroup = one bin, all Fourier orders s and scattering orders ig):
+//  * the radiance field L(6N rows x NT+1 levels) of the current scattering order lives in LDS for the
+//    whole solve, laid out [level][row] (row contiguous) with a level stride of KP+2 doubles;
+//  * the order-ig source S = M_s (XDEL o L) [+ M_ray,s (YDEL o L) for s <= 2] is a dense
+//    [6N x 6N] x [6N x (NT+1)] FP64 contraction run on v_mfma_f64_16x16x4_f64: each of the 4 waves owns
+//    RTW row tiles x CT column tiles of accumulators (registers); the operator M_s streams from L2/MALL
+//    in pre-packed A-fragment order (1 KiB contiguous per wave load), the B fragments come from LDS and
+//    are scaled by XDEL/YDEL of their level in registers;
+//  * S overwrites L in LDS, then one thread per (Stokes, direction) row runs the layer-by-layer formal
+//    solution (SOS_INTEGR_EPOPT) in place, using attenuations exp(-dtau/mu) precomputed once per bin;
+//  * stop tests are three max-reductions per scattering order fused into one wavefront-shuffle +
+//    LDS reduction; the geometric-series tail, the Fourier accumulation and the Fourier stop are
+//    per-thread register state.
+// HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
+// or L2/MALL-resident operator reads shared by all bins.
+#include "sos_common.h"
+#include "kernels.h"
+
+#define SOSGPU_E_UNSUPPORTED -3
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Force a value the whole wave agrees on into scalar registers, so that the loop exits it decides are
+// uniform branches (keeps s / ig / operator pointers in SGPRs instead of per-lane VGPRs).
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+}
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// max over the workgroup of three values at once (red: 12 doubles of LDS); contains two barriers
+__device__ __forceinline__ void block_max3(double &a, double &b, double &c, double *red)
+{
+    a = wave_max(a); b = wave_max(b); c = wave_max(c);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w * 3] = a; red[w * 3 + 1] = b; red[w * 3 + 2] = c; }
+    __syncthreads();
+    a = uniform_f64(fmax(fmax(red[0], red[3]), fmax(red[6], red[9])));
+    b = uniform_f64(fmax(fmax(red[1], red[4]), fmax(red[7], red[10])));
+    c = uniform_f64(fmax(fmax(red[2], red[5]), fmax(red[8], red[11])));
+    __syncthreads();
+}
+
+// one term of SOS_PARAM_CONV (SOS_OS.F:3434-3453)
+__device__ __forceinline__ double conv_term(double a, double d, double g, double x3)
+{
+    if (a != 0.0 && d != 0.0 && x3 != 0.0) {
+        const double gd = g / d;
+        const double y = ((gd - d / a) / ((1 - gd) * (1 - gd)) * (g / x3));
+        return fabs(y);
+    }
+    return 0.;
+}
+// SOS_AJOUT_QUEUE (SOS_OS.F:3959-3975)
+__device__ __forceinline__ double queue_term(double d, double g)
+{
+    return (d == 0.) ? 0. : g / (1 - g / d);
+}
+
+// Source contraction: acc += sum over passes of Mp_pass * (scale_pass o field).  Pass 0 = aerosol
+// operator with XDEL, pass 1 = molecular operator with YDEL (s <= 2 only).  One copy of the MFMA loop.
+template <int RTW, int CT>
+__device__ __forceinline__ void gemm_source(v4d (&acc)[RTW][CT], const double *__restrict__ mp0,
+                                            const double *__restrict__ mp1, int pass_lo, int pass_hi, int ks2,
+                                            const double *fld, int CS, const double *scale0, const double *scale1,
+                                            int lane, int wv)
+{
+    const size_t rts = (size_t)ks2 * 64;     // v2d stride between row tiles
+    const double *bp[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) bp[ct] = fld + (size_t)(ct * 16 + (lane & 15)) * CS + 2 * (lane >> 4);
+#pragma unroll 1
+    for (int pass = pass_lo; pass < pass_hi; pass++) {
+        const v2d *ap = reinterpret_cast<const v2d *>(pass ? mp1 : mp0) + ((size_t)(wv * RTW) * ks2) * 64 + lane;
+        const double *scale = pass ? scale1 : scale0;
+        double sc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) sc[ct] = scale[ct * 16 + (lane & 15)];
+        v2d a_cur[RTW], a_nxt[RTW];
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++) { a_cur[rt] = ap[rt * rts]; a_nxt[rt] = a_cur[rt]; }
+#pragma unroll 1
+        for (int m = 0; m < ks2; m++) {
+            if (m + 1 < ks2) {
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++) a_nxt[rt] = ap[rt * rts + (size_t)(m + 1) * 64];
+            }
+            v2d bb[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                bb[ct] = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
+                bb[ct].x *= sc[ct];
+                bb[ct].y *= sc[ct];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[rt].x, bb[ct].x, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[rt].y, bb[ct].y, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++) a_cur[rt] = a_nxt[rt];
+        }
+    }
+}
+
+template <int RTW, int CT>
+__global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
+{
+    extern __shared__ double smem[];
+    constexpr int COLS = 16 * CT;
+    const int N = cx.n, R6 = cx.r6, KP = cx.kp, CS = cx.kp + 2, W = cx.w;
+    double *fld = smem;                    // [COLS][CS]   field / source, [level][row]
+    double *att = fld + COLS * CS;         // [COLS][N]    exp(-dtau_i/mu_j), layer i = levels i..i+1
+    double *dtau = att + COLS * N;         // [COLS] each:
+    double *idtau = dtau + COLS;
+    double *xdel = idtau + COLS;
+    double *ydel = xdel + COLS;
+    double *ch = ydel + COLS;
+    double *fco = ch + COLS;
+    double *hh = fco + COLS;
+    double *gnd = hh + COLS;               // [3][N] down-going field at the ground, order ig-1
+    double *i3s = gnd + 3 * N;             // [2N]   I3 of the I rows (flux integrals)
+    double *red = i3s + 2 * N;             // [16]
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool active = t < R6;
+    const int c = active ? t / (2 * N) : 0;
+    const int d = active ? t % (2 * N) : 0;
+    const bool up = d < N;
+    const int jj = up ? d : d - N;         // 0-based index of |direction|
+    const double mu = cx.mu[jj];
+    const int recoff = c * W + N + (up ? (jj + 1) : -(jj + 1));
+    const size_t mper = (size_t)cx.rtp * cx.ks2 * 128;
+    const int S1 = cx.smax + 1;
+
+    {   // one workgroup = one bin (grid = nb): no bin loop, so per-bin constants are not kept live elsewhere
+        const int b = blockIdx.x;
+        const int nt = uniform_i32(bn.nt[b]);
+        const int iborm = uniform_i32(bn.iborm[b]);
+        const int jout = uniform_i32(bn.jout ? bn.jout[b] : 0);
+        const double zz = uniform_f64(jout ? bn.zz[b] : 0.);
+        const int jlo = jout ? jout - 1 : -1, jhi = jout ? jout : -1;
+        // shape guard (uniform): a malformed bin is flagged (norders = -1), never indexed out of bounds
+        if (nt < 1 || nt >= COLS || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
+            if (t == 0) bn.norders[b] = -1;
+            return;
+        }
+        const double *pf = bn.prof + (size_t)b * 3 * bn.lp;
+        double *recb = bn.rec + (size_t)b * S1 * 3 * W;
+
+        __syncthreads();
+        for (int i = t; i < COLS * CS; i += 256) fld[i] = 0.;
+        if (t < COLS) {
+            const bool in = t <= nt;
+            hh[t] = in ? pf[t] : 0.;
+            xdel[t] = in ? pf[bn.lp + t] : 0.;
+            ydel[t] = in ? pf[2 * bn.lp + t] : 0.;
+        }
+        __syncthreads();
+        const double htot = uniform_f64(hh[nt]);
+        if (t < COLS) {
+            if (t < nt) { const double dt = hh[t + 1] - hh[t]; dtau[t] = dt; idtau[t] = 1.0 / dt; }
+            else { dtau[t] = 0.; idtau[t] = 0.; }
+            ch[t] = (t <= nt) ? exp(-hh[t] / cx.mus) / 4. : 0.;                               // SOS_OS.F:837-839
+            fco[t] = (t <= nt) ? (exp(-2. * htot / cx.mus) / 4.) * exp(hh[t] / cx.mus) : 0.;  // SOS_OS.F:3219,3278
+        }
+        const int has_aer = uniform_i32(__syncthreads_or((t <= nt && t < COLS && xdel[t] != 0.) ? 1 : 0));
+        for (int i = t; i < nt * N; i += 256) att[i] = exp(-dtau[i / N] / cx.mu[i % N]);      // SOS_OS.F:2291,2335
+        // bin-constant exponentials of the ground boundary terms (SOS_OS.F:979,985,1068-1077)
+        const double e_sun = uniform_f64(exp(-htot / cx.mus));
+        double e_mu = 0., e_lo = 0., e_hi = 0.;
+        if (cx.imat_surf && active && up) {
+            e_mu = exp(-htot / mu);
+            if (jout) { e_lo = exp(-(htot - hh[jlo]) / mu); e_hi = exp(-(htot - hh[jhi]) / mu); }
+        }
+        __syncthreads();
+
+        // per-thread formal solution of its row, in place over the source held in fld (SOS_INTEGR_EPOPT,
+        // SOS_OS.F:2279-2354).  bcv = value at the ground for up-going rows.
+        double xb, xlo = 0., xhi = 0.;
+        auto scan_row = [&](double bcv) {
+            if (!active) { xb = 0.; return; }
+            const double *arow = att + jj;
+            if (up) {
+                double z = bcv;
+                double snext = fld[nt * CS + t];
+                fld[nt * CS + t] = z;
+                if (jhi == nt) xhi = z;
+#pragma unroll 1
+                for (int i = nt - 1; i >= 0; --i) {
+                    const double a_t = arow[i * N], dt = dtau[i];
+                    const double bq = fld[i * CS + t];
+                    const double a = (snext - bq) * idtau[i];
+                    z = z * a_t + (1.0 - a_t) * (a * mu + bq) - a * (a_t * dt);
+                    fld[i * CS + t] = z;
+                    snext = bq;
+                    if (i == jlo) xlo = z;
+                    if (i == jhi) xhi = z;
+                }
+                xb = z;
+            } else {
+                double z = 0.;
+                double sprev = fld[t];
+                fld[t] = 0.;
+                if (jlo == 0) xlo = 0.;
+                const double rmuk = -mu;
+#pragma unroll 1
+                for (int i = 1; i <= nt; ++i) {
+                    const double a_t = arow[(i - 1) * N], dt = dtau[i - 1];
+                    const double bq = fld[i * CS + t];
+                    const double a = (bq - sprev) * idtau[i - 1];
+                    z = z * a_t + (1.0 - a_t) * (a * rmuk + bq) + a * (a_t * dt);
+                    fld[i * CS + t] = z;
+                    sprev = bq;
+                    if (i == jlo) xlo = z;
+                    if (i == jhi) xhi = z;
+                }
+                xb = z;
+                gnd[c * N + jj] = z;
+            }
+        };
+
+        double i4 = 0., i5 = 0.;
+        double sign = -1.;
+        int nord = 0;
+        for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
+            sign = -sign;
+            const float *rs = cx.imat_surf ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
+            // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239)
+            auto ground_bc = [&]() -> double {
+                if (!(active && up)) return 0.;
+                double v = 0., xr = 0.;
+                if (c == 0 && cx.ro != 0. && s == 0) {
+                    double lsol = 0.;
+#pragma unroll 1
+                    for (int j = 0; j < N; j++) lsol = lsol + cx.ga[j] * gnd[j] * cx.mu[j];
+                    lsol = 2 * lsol * cx.ro;
+                    v = lsol; xr = lsol;
+                }
+                if (cx.imat_surf) {
+                    double acc2 = 0.;
+                    const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + (size_t)jj * N;
+                    const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + (size_t)jj * N;
+                    const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + (size_t)jj * N;
+#pragma unroll 1
+                    for (int j = 0; j < N; j++) {
+                        double q0 = r0[j], q1 = r1[j], q2 = r2[j];
+                        if (!cx.ipolar) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }   // SOS_OS.F:928-941
+                        acc2 = acc2 + cx.ga[j] * (gnd[j] * q0 + gnd[N + j] * q1 + gnd[2 * N + j] * q2);
+                    }
+                    v = acc2 * (2 / mu) + xr;
+                }
+                if (cx.ifresnel == 1) {
+                    const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
+                    if (c == 0) v = v + f11 * gnd[jj] + f12 * gnd[N + jj];
+                    else if (c == 1) v = v + f12 * gnd[jj] + f11 * gnd[N + jj];
+                    else v = v + f33 * gnd[2 * N + jj];
+                }
+                return v;
+            };
+
+            // ---- scattering order 1 ------------------------------------------------------------
+            const double *svp = cx.sv + (size_t)s * 4 * KP;
+            if (active) {
+                const double sva = svp[t], svr = svp[KP + t];
+                const double sfa = svp[2 * KP + t], sfr = svp[3 * KP + t];
+#pragma unroll 1
+                for (int i = 0; i <= nt; i++) {
+                    double v = ch[i] * (sva * xdel[i] + svr * ydel[i]);              // SOS_OS.F:2557-2559
+                    if (cx.ifresnel == 1 && (up ? (i < nt) : (i >= 1)))
+                        v = v + fco[i] * (sfa * xdel[i] + sfr * ydel[i]);            // SOS_OS.F:3280-3289
+                    fld[i * CS + t] = v;
+                }
+            }
+            double bc = 0., dirterm = 0.;
+            if (active && up) {                                                      // SOS_OS.F:970-992
+                double xr = 0.;
+                if (c == 0 && cx.ro != 0. && s == 0) { bc = cx.ro * cx.mus * e_sun; xr = bc; }
+                if (cx.imat_surf) {
+                    const double rr = e_sun / mu;
+                    double r = rs[(size_t)(c * 3) * N * N + (size_t)jj * N + (cx.n0 - 1)];
+                    if (!cx.ipolar && c) r = 0.;
+                    bc = bc + r * rr;
+                    dirterm = bc - xr;                                               // SOS_OS.F:1070-1072
+                }
+            }
+            scan_row(bc);
+            double rii = 0., riilo = 0., riihi = 0.;
+            if (cx.imat_surf && active && up) {                                      // SOS_OS.F:1062-1084
+                rii = e_mu * dirterm;
+                riilo = e_lo * dirterm;
+                riihi = e_hi * dirterm;
+            }
+            double i3 = xb, a1 = 0., d1 = xb, g1 = 0.;                               // SOS_OS.F:1094-1137
+            double i3lo = xlo, dlo = xlo, i3hi = xhi, dhi = xhi;
+            __syncthreads();
+            bc = ground_bc();
+
+            // ---- scattering orders >= 2 --------------------------------------------------------
+            int ig = 1, iglast = 1;
+            for (;;) {
+                ig = ig + 1;
+                if (ig > cx.igmax) break;
+                iglast = ig;
+                // source function: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
+                v4d acc[RTW][CT];
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++) acc[rt][ct] = (v4d){0., 0., 0., 0.};
+                __syncthreads();
+                gemm_source<RTW, CT>(acc, cx.mp_aer + (size_t)s * mper, cx.mp_ray + (size_t)(s <= 2 ? s : 0) * mper,
+                                     has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2, fld, CS, xdel, ydel, lane, wv);
+                __syncthreads();
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++) {
+                        const int col = ct * 16 + (lane & 15);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int row = (wv * RTW + rt) * 16 + (lane >> 4) + 4 * e;
+                            if (row < R6 && col <= nt) fld[col * CS + row] = acc[rt][ct][e];
+                        }
+                    }
+                __syncthreads();
+                scan_row(bc);                                                        // SOS_OS.F:1244
+                g1 = xb;
+                const double i3n = i3 + g1;
+                double y1 = (ig != 2) ? conv_term(a1, d1, g1, i3) : 0.;              // SOS_PARAM_CONV
+                double y2 = fabs(g1);                                                // SOS_ARRET_DIFFUS_1
+                double y3 = (i3n != 0.0) ? fabs(g1 / i3n) : 0.;                      // SOS_ARRET_DIFFUS_2
+                block_max3(y1, y2, y3, red);
+                bc = ground_bc();
+                if (ig != 2 && !(y1 > cx.thr_cv)) {                                  // SOS_OS.F:1293-1315
+                    i3 = i3 + queue_term(d1, g1);
+                    i3lo = i3lo + queue_term(dlo, xlo);
+                    i3hi = i3hi + queue_term(dhi, xhi);
+                    break;
+                }
+                a1 = d1; d1 = g1; dlo = xlo; dhi = xhi;                              // SOS_OS.F:1323-1363
+                i3 = i3n; i3lo = i3lo + xlo; i3hi = i3hi + xhi;
+                if (!(y2 > cx.thr_val)) break;                                       // SOS_OS.F:1370
+                if (!(y3 > cx.thr_sum)) break;                                       // SOS_OS.F:1389
+                if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
+            }
+            if (cx.imat_surf && active && up) { i3 = i3 - rii; i3lo = i3lo - riilo; i3hi = i3hi - riihi; }  // :1421-1439
+
+            if (s == 0) {                                                            // SOS_OS.F:1447-1456
+                if (active && c == 0) i3s[d] = i3;
+                __syncthreads();
+                if (t == 0) {
+                    double em = 0., ep = 0.;
+                    for (int j = 0; j < N; j++) {
+                        em = em + cx.mu[j] * cx.ga[j] * i3s[N + j];
+                        ep = ep + cx.mu[j] * cx.ga[j] * i3s[j];
+                    }
+                    bn.flux[2 * b] = em * 2 / cx.mus;
+                    bn.flux[2 * b + 1] = ep * 2 / cx.mus;
+                }
+            }
+            const double coef = (s == 0) ? 1. : 2.;                                  // SOS_OS.F:1460-1473
+            i4 = i4 + coef * i3;
+            i5 = i5 + coef * i3 * sign;
+            if (active) {                                                            // SOS_OS.F:1484-1534,1572
+                const double outv = jout ? ((1 - zz) * i3lo + zz * i3hi) : i3;
+                recb[(size_t)s * 3 * W + recoff] = outv;
+                if (up && jj == 0) recb[(size_t)s * 3 * W + c * W + N] = 0.;
+            }
+            if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
+            nord = s + 1;
+            double z1 = 0., z2 = 0., z3 = 0.;                                        // SOS_ARRET_FOURIER
+            if (active) {
+                if (i4 != 0.0) z1 = fabs(i3 / i4);
+                if (i5 != 0.0) z2 = fabs(i3 / i5);
+            }
+            block_max3(z1, z2, z3, red);
+            if (!(fmax(z1, z2) > cx.thr_sf)) break;                                  // SOS_OS.F:1585
+        }
+        // orders not run: zero records and counts
+        for (int i = t + nord * 3 * W; i < S1 * 3 * W; i += 256) recb[i] = 0.;
+        for (int i = t + nord; i < S1; i += 256) bn.iglast[(size_t)b * S1 + i] = 0;
+        if (t == 0) bn.norders[b] = nord;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// variant table
+// ---------------------------------------------------------------------------------------------
+static size_t lds_bytes_for(int n, int ct)
+{
+    const int cols = 16 * ct;
+    const int kp = sos_round_up(6 * n, 8);
+    const size_t dbl = (size_t)cols * (kp + 2) + (size_t)cols * n + 7 * cols + 3 * n + 2 * n + 16;
+    return dbl * sizeof(double);
+}
+
+int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes)
+{
+    if (n < 1 || n > 85 || nt_max < 1) return SOSGPU_E_UNSUPPORTED;
+    const int rt = (6 * n + 15) / 16;
+    const int r = (rt + 3) / 4;
+    int c;
+    if (nt_max + 1 <= 32) c = 2;
+    else if (nt_max + 1 <= 64) c = 4;
+    else return SOSGPU_E_UNSUPPORTED;
+    const size_t lb = lds_bytes_for(n, c);
+    if (lb > 160 * 1024) return SOSGPU_E_UNSUPPORTED;
+    if (rtw) *rtw = r;
+    if (ct) *ct = c;
+    if (lds_bytes) *lds_bytes = lb;
+    return 0;
+}
+
+template <int RTW, int CT>
+static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
+{
+    auto kern = k_sos_os<RTW, CT>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return -2;
+    const int grid = bn.nb;
+    kern<<<grid, 256, lds, st>>>(cx, bn);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st)
+{
+    int rtw, ct;
+    size_t lds;
+    const int rc = sos_os_variant(cx.n, nt_max, &rtw, &ct, &lds);
+    if (rc) return rc;
+    if (cx.rtp != 4 * rtw) return SOSGPU_E_UNSUPPORTED;
+#define V(R, C) if (rtw == R && ct == C) return launch_variant<R, C>(cx, bn, lds, st);
+    V(1, 2) V(2, 2) V(3, 2) V(4, 2) V(5, 2) V(6, 2) V(7, 2) V(8, 2)
+    V(1, 4) V(2, 4) V(3, 4) V(4, 4) V(5, 4) V(6, 4)
+#undef V
+    return SOSGPU_E_UNSUPPORTED;
+}

@@ -1,0 +1,181 @@
+"""Host-side driver of the MI355X hot path: one `SosContext` per wavelength, batches of CKD bins solved
+by the fused HIP kernel, aggregation on device.  torch is used for device memory and streams only; all
+arithmetic happens in libsosgpu.so (capi.py), and there is no CPU fallback.
+
+Mirrors the reference per-wavelength sequence of SOS_PROC (src/SOS_PROC.F:3423-3594):
+  SOS_PREPA_OS -> [per bin: SOS (truncation rescale) -> SOS_OS -> SOS_AGGREGATE].
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .synth import MDF_DEFAULT
+
+
+def _dev_f64(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float64).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(device)
+
+
+def _dev_i32(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.int32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(device)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class SosContext:
+    """Everything SOS_OS needs that does not depend on the CKD bin (angles, phase-matrix expansion,
+    surface), resident on one GPU, with the Fourier kernels of every order precomputed
+    (sosgpu_noyaux, replaces SOS_NOYAUX SOS_OS.F:1857)."""
+
+    def __init__(self, mu, ga, n0, alpha, beta, gamma, zeta, *, iborm_max=None, ro=0.0, imat_surf=0,
+                 ifresnel=0, ind_surf=1.34, ron=MDF_DEFAULT, ipolar=1, igmax=100, rsurf=None, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SosContext needs a GPU (gfx950); there is no CPU fallback in the product path")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.n = int(len(mu))
+        self.w = 2 * self.n + 1
+        self.os_nb = int(len(beta) - 1)
+        self.smax = self.os_nb if iborm_max is None else int(iborm_max)
+        self.n0 = int(n0)
+        self.mu = np.ascontiguousarray(mu, dtype=np.float64)
+        self.ga = np.ascontiguousarray(ga, dtype=np.float64)
+        coefs = [np.ascontiguousarray(x, dtype=np.float64) for x in (alpha, beta, gamma, zeta)]
+        for x in coefs:
+            if len(x) != self.os_nb + 1:
+                raise ValueError("alpha/beta/gamma/zeta must all have os_nb+1 entries")
+        wv = capi.Wave(n=self.n, os_nb=self.os_nb, n0=self.n0, imat_surf=int(imat_surf), ifresnel=int(ifresnel),
+                       ipolar=int(ipolar), igmax=int(igmax), reserved=0, ro=float(ro), ind_surf=float(ind_surf),
+                       ron=float(ron))
+        self._h = C.c_void_p()
+        L = capi.lib()
+        dp = lambda a: a.ctypes.data_as(C.c_void_p)
+        capi.check(L.sosgpu_create(C.byref(self._h), self.device.index or 0, C.byref(wv), dp(self.mu), dp(self.ga),
+                                   dp(coefs[0]), dp(coefs[1]), dp(coefs[2]), dp(coefs[3]), self.smax),
+                   "sosgpu_create")
+        self._rsurf = None
+        if int(imat_surf) == 1:
+            if rsurf is None:
+                raise ValueError("imat_surf=1 needs rsurf[smax+1][9][N][N] (float32)")
+            if isinstance(rsurf, torch.Tensor):
+                r = rsurf.to(device=self.device, dtype=torch.float32).contiguous()
+            else:
+                r = torch.from_numpy(np.ascontiguousarray(rsurf, dtype=np.float32)).to(self.device)
+            if tuple(r.shape) != (self.smax + 1, 9, self.n, self.n):
+                raise ValueError("rsurf shape %s != %s" % (tuple(r.shape), (self.smax + 1, 9, self.n, self.n)))
+            self._rsurf = r
+            capi.check(L.sosgpu_set_surface_matrices(self._h, _ptr(r)), "sosgpu_set_surface_matrices")
+        self.noyaux()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def noyaux(self):
+        capi.check(capi.lib().sosgpu_noyaux(self._h, self._stream()), "sosgpu_noyaux")
+
+    def noyaux_fetch(self, is_):
+        """Kernels of Fourier order is_ in the reference layout (parity accessor)."""
+        w = self.w
+        out = np.zeros(6 * w * w + 3 * w)
+        torch.cuda.synchronize(self.device)
+        capi.check(capi.lib().sosgpu_noyaux_fetch(self._h, int(is_), out.ctypes.data_as(C.c_void_p)), "sosgpu_noyaux_fetch")
+        names = ["BP", "GR", "GT", "ARR", "ART", "ATT"]
+        d = {k: out[i * w * w:(i + 1) * w * w].reshape(w, w) for i, k in enumerate(names)}
+        for i, k in enumerate(["XPL", "XRL", "XTL"]):
+            d[k] = out[6 * w * w + i * w:6 * w * w + (i + 1) * w]
+        return d
+
+    def upload_bins(self, h, xdel, ydel, nt=None, iborm=None, zout=-1.0, zprof=None):
+        """Pack per-bin profiles (after the SOS.F rescale) into the device layout of sosgpu_os_solve.
+        h/xdel/ydel: [nb][L] arrays (ragged bins: pass nt[nb] and pad)."""
+        h = np.atleast_2d(np.asarray(h, dtype=np.float64))
+        xdel = np.atleast_2d(np.asarray(xdel, dtype=np.float64))
+        ydel = np.atleast_2d(np.asarray(ydel, dtype=np.float64))
+        nb, lmax = h.shape
+        nt = np.full(nb, lmax - 1, dtype=np.int32) if nt is None else np.asarray(nt, dtype=np.int32)
+        lp = int(-(-lmax // 16) * 16)
+        prof = np.zeros((nb, 3, lp))
+        prof[:, 0, :lmax], prof[:, 1, :lmax], prof[:, 2, :lmax] = h, xdel, ydel
+        if iborm is None:
+            # SOS.F:549-550: IBORM = 2 for a purely molecular bin, OS_NB otherwise
+            iborm = np.where(np.any(xdel != 0.0, axis=1), self.smax, min(2, self.smax)).astype(np.int32)
+        iborm = np.broadcast_to(np.asarray(iborm, dtype=np.int32), (nb,)).copy()
+        jout = zz = None
+        if zout != -1.0:
+            # SOS_OS.F:1514-1520: first level J with ZOUT >= ZPROF(J), linear weight ZZ
+            zprof = np.atleast_2d(np.asarray(zprof, dtype=np.float64))
+            jout = np.zeros(nb, dtype=np.int32)
+            zz = np.zeros(nb)
+            for b in range(nb):
+                j = 1
+                while zout < zprof[b, j]:
+                    j += 1
+                jout[b] = j
+                zz[b] = (zout - zprof[b, j - 1]) / (zprof[b, j] - zprof[b, j - 1])
+        d = self.device
+        return dict(nb=nb, lp=lp, nt=_dev_i32(nt, d), iborm=_dev_i32(iborm, d), prof=_dev_f64(prof, d),
+                    jout=None if jout is None else _dev_i32(jout, d), zz=None if zz is None else _dev_f64(zz, d))
+
+    def alloc_outputs(self, nb):
+        d = self.device
+        return dict(rec=torch.empty((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),
+                    norders=torch.empty(nb, dtype=torch.int32, device=d),
+                    iglast=torch.empty((nb, self.smax + 1), dtype=torch.int32, device=d),
+                    flux=torch.zeros((nb, 2), dtype=torch.float64, device=d))
+
+    def solve(self, bins, out=None):
+        """Run the fused SOS_OS kernel on a batch of bins already resident in HBM (upload_bins)."""
+        if out is None:
+            out = self.alloc_outputs(bins["nb"])
+        capi.check(capi.lib().sosgpu_os_solve(self._h, bins["nb"], bins["lp"], _ptr(bins["nt"]), _ptr(bins["iborm"]),
+                                              _ptr(bins["prof"]), _ptr(bins["jout"]), _ptr(bins["zz"]),
+                                              _ptr(out["rec"]), _ptr(out["norders"]), _ptr(out["iglast"]),
+                                              _ptr(out["flux"]), self._stream()), "sosgpu_os_solve")
+        return out
+
+    def last_solve_ms(self):
+        ms = C.c_float(0)
+        capi.check(capi.lib().sosgpu_last_solve_ms(self._h, C.byref(ms)), "sosgpu_last_solve_ms")
+        return ms.value
+
+    def solve_flops(self, bins, out):
+        fl = C.c_double(0)
+        torch.cuda.synchronize(self.device)
+        capi.check(capi.lib().sosgpu_os_flops(self._h, bins["nb"], _ptr(bins["nt"]), _ptr(out["norders"]),
+                                              _ptr(out["iglast"]), C.byref(fl)), "sosgpu_os_flops")
+        return fl.value
+
+    def aggregate(self, out, aik, seg=None, scal=None):
+        """SOS_AGGREGATE over segments of bins (default: all bins = one wavelength).  Returns
+        (rec[nseg][smax+1][3][W], scal[nseg][8]) on device; see include/sosgpu.h for scal."""
+        nb = out["rec"].shape[0]
+        d = self.device
+        seg_t = _dev_i32(np.array([0, nb], dtype=np.int32) if seg is None else seg, d)
+        nseg = seg_t.numel() - 1
+        aik_t = _dev_f64(aik, d)
+        scal_t = torch.zeros((nb, 4), dtype=torch.float64, device=d) if scal is None else _dev_f64(scal, d)
+        o_rec = torch.empty((nseg, self.smax + 1, 3, self.w), dtype=torch.float64, device=d)
+        o_scal = torch.empty((nseg, 8), dtype=torch.float64, device=d)
+        capi.check(capi.lib().sosgpu_aggregate(self._h, nseg, _ptr(seg_t), _ptr(aik_t), _ptr(out["rec"]),
+                                               _ptr(out["norders"]), _ptr(out["flux"]), _ptr(scal_t),
+                                               _ptr(o_rec), _ptr(o_scal), self._stream()), "sosgpu_aggregate")
+        return o_rec, o_scal
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            capi.lib().sosgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
