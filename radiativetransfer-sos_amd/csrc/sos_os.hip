@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
         double e_mu = 0., e_lo = 0., e_hi = 0.;
         if (cx.imat_surf && active && up) {
             e_mu = exp(-htot / mu);
+            e_lo = exp(-(htot - hh[0]) / mu);     // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
             if (jout) { e_lo = exp(-(htot - hh[jlo]) / mu); e_hi = exp(-(htot - hh[jhi]) / mu); }
         }
         __syncthreads();
@@ -365,7 +366,10 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
                 if (!(y3 > cx.thr_sum)) break;                                       // SOS_OS.F:1389
                 if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
             }
-            if (cx.imat_surf && active && up) { i3 = i3 - rii; i3lo = i3lo - riilo; i3hi = i3hi - riihi; }  // :1421-1439
+            // SOS_OS.F:1421-1439.  The record is built from I3OUT (minus RIIOUT at the output level), the stop
+            // tests and fluxes from I3 (minus RII): the two differ by exp(H(0)/mu) on the direct term.
+            double i3out0 = i3;
+            if (cx.imat_surf && active && up) { i3out0 = i3 - riilo; i3 = i3 - rii; i3lo = i3lo - riilo; i3hi = i3hi - riihi; }
 
             if (s == 0) {                                                            // SOS_OS.F:1447-1456
                 if (active && c == 0) i3s[d] = i3;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
             i4 = i4 + coef * i3;
             i5 = i5 + coef * i3 * sign;
             if (active) {                                                            // SOS_OS.F:1484-1534,1572
-                const double outv = jout ? ((1 - zz) * i3lo + zz * i3hi) : i3;
+                const double outv = jout ? ((1 - zz) * i3lo + zz * i3hi) : i3out0;
                 recb[(size_t)s * 3 * W + recoff] = outv;
                 if (up && jj == 0) recb[(size_t)s * 3 * W + c * W + N] = 0.;
             }

@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of the CKD-bin axis (one process per GPU, torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" on CPU for tests).
+
+The bin loop of SOS_PROC (src/SOS_PROC.F:3459-3594) is embarrassingly parallel: every rank solves a
+contiguous slice of the bin list and forms its AIK-weighted partial sums locally; the only exchange is
+ONE all-reduce(sum, fp64) per wavelength/band of the packed buffer
+    [ (smax+1)*3*W Fourier records | 8 scalars ]
+(~161 KB at N=41, 81 orders: latency-bound on xGMI), which replaces the serial file-based accumulation of
+SOS_AGGREGATE (src/SOS_AGGREGATE.F:372-488).  The -ln of the three transmissions is applied after the
+reduce (SOS_AGGREGATE.F:467-488).
+"""
+import numpy as np
+import torch
+
+
+def shard_range(nb, rank, world):
+    """Contiguous slice [lo, hi) of nb bins for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(nb, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_partial(rec, scal):
+    """rec [nseg][S][3][W], scal [nseg][8] -> one flat fp64 buffer per segment [nseg][S*3*W + 8]."""
+    nseg = rec.shape[0]
+    return torch.cat([rec.reshape(nseg, -1), scal.reshape(nseg, -1)], dim=1).contiguous()
+
+
+def unpack_partial(buf, rec_shape):
+    nseg = buf.shape[0]
+    n = int(np.prod(rec_shape[1:]))
+    return buf[:, :n].reshape((nseg,) + tuple(rec_shape[1:])), buf[:, n:n + 8]
+
+
+def all_reduce_partial(buf, group=None):
+    """Sum the packed partials over ranks.  Element 7 of the scalar block is max(norders): reduced
+    with MAX in a second tiny collective only when more than one rank exists."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return buf
+    nmax = buf[:, -1].clone()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
+    buf[:, -1] = nmax
+    return buf
+
+
+def finish_scalars(scal):
+    """scal [nseg][8] (summed over all bins/ranks) -> dict of per-segment results as SOS_AGGREGATE leaves
+    them: TDIFMUS, EMOINS, EPLUS, TTOT_TRONC, TTOT_VRAI, TAUOUT, sum(AIK), n_orders."""
+    s = scal.detach().cpu().numpy() if isinstance(scal, torch.Tensor) else np.asarray(scal)
+    with np.errstate(divide="ignore"):
+        return dict(tdifmus=s[:, 0], emoins=s[:, 1], eplus=s[:, 2], ttot_tronc=-np.log(s[:, 3]),
+                    ttot_vrai=-np.log(s[:, 4]), tauout=-np.log(s[:, 5]), sum_aik=s[:, 6],
+                    n_orders=s[:, 7].astype(np.int32))
