@@ -188,27 +188,24 @@ def sos_os(rmu, ga, os_nb, h, xdel, ydel, alpha, beta, gamma, zeta, *, n0, tetas
 _RE_IS = re.compile(r"Fourier series expansion order: IS =\s+(\d+)")
 _RE_GEO = re.compile(r"Convergence in geometric series from IG =\s+(\d+)")
 _RE_END = re.compile(r"for IG =\s+(\d+)")
-_RE_MAX = re.compile(r"the maximal order : IGMAX")
+_RE_MAX = re.compile(r"because of reaching")
 
 
 def parse_ig_counts(log, igmax):
     """Last scattering order IG computed for each Fourier order, from the TRACE log messages
-    (SOS_OS.F:1306-1309, 1374-1379, 1393-1398, 1410-1414)."""
+    (SOS_OS.F:1306-1309, 1374-1379, 1393-1398, 1410-1414).  List-directed output may wrap lines, so
+    each Fourier-order chunk is whitespace-collapsed before matching."""
+    chunks = _RE_IS.split(log)[1:]          # [is, text, is, text, ...]
     counts = []
-    cur = None
-    for line in log.splitlines():
-        m = _RE_IS.search(line)
+    for text in chunks[1::2]:
+        flat = re.sub(r"\s+", " ", text)
+        m = _RE_GEO.search(flat) or _RE_END.search(flat)
         if m:
-            cur = int(m.group(1))
+            counts.append(int(m.group(1)))
+        elif _RE_MAX.search(flat):
+            counts.append(igmax)
+        else:
             counts.append(-1)
-            continue
-        if cur is None:
-            continue
-        m = _RE_GEO.search(line) or _RE_END.search(line)
-        if m and counts[-1] < 0:
-            counts[-1] = int(m.group(1))
-        elif _RE_MAX.search(line) and counts[-1] < 0:
-            counts[-1] = igmax
     return counts
 
 
