@@ -1,0 +1,98 @@
+"""CPU tests of the checker itself: the C restatement (oracle/) against the committed golden vectors
+(generated from the reference Fortran) and, where oracle/_ref is present, against the reference live."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, "sos_os_%s.npz" % name))
+
+
+@pytest.mark.parametrize("name", cases.ALL_CASES)
+def test_inputs_reproducible(name):
+    """The seeded input generators regenerate exactly the arrays the goldens were made from."""
+    g = load_golden(name)
+    case = cases.make_case(name)
+    assert np.array_equal(g["rmu"], case["rmu"]) and np.array_equal(g["ga"], case["ga"])
+    assert int(g["n0"]) == case["n0"] and int(g["iborm"]) == case["iborm"]
+    for k, a in zip(["alpha", "beta", "gamma", "zeta"], case["coefs"]):
+        assert np.array_equal(g[k], a)
+    for b, (h, x, y, z) in enumerate(case["bins"]):
+        assert np.array_equal(g["h%d" % b], h) and np.array_equal(g["xdel%d" % b], x)
+        assert np.array_equal(g["ydel%d" % b], y) and np.array_equal(g["zprof%d" % b], z)
+
+
+@pytest.mark.parametrize("name", cases.ALL_CASES)
+def test_oracle_vs_golden(oracle, name):
+    """Restatement == reference Fortran outputs: same Fourier/scattering-order counts, records to 1e-12
+    (they are bit-identical in the authoring container; the slack covers a different libm)."""
+    g = load_golden(name)
+    case = cases.make_case(name)
+    for b in range(int(g["nbins"])):
+        r = cases.run_cpu(oracle, case, b)
+        assert r["ier"] == 0
+        assert np.array_equal(r["ig_counts"], g["ig%d" % b]), (name, b)
+        cases.compare_records(r["records"], g["rec%d" % b], 1e-12, "%s bin %d" % (name, b))
+        assert np.allclose([r["emoins"], r["eplus"]], g["flux%d" % b], rtol=1e-12, atol=0)
+
+
+def test_oracle_noyaux_vs_golden(oracle):
+    g = np.load(os.path.join(GOLD, "noyaux_n13.npz"))
+    mu, n0 = g["mu"], int(g["n0"])
+    for is_ in (0, 1, 2, 3, 12, 24):
+        k = oracle.noyaux(is_, -mu[n0 - 1], mu, 24, g["alpha"], g["beta"], g["gamma"], g["zeta"])
+        for key in ["BP", "GR", "GT", "ARR", "ART", "ATT", "XPL", "XRL", "XTL"]:
+            ref = g["is%d_%s" % (is_, key)]
+            assert np.abs(k[key] - ref).max() <= 1e-13 * (np.abs(ref).max() + 1e-300), (is_, key)
+
+
+def test_oracle_vs_reference_live(oracle):
+    """Only where the compiled reference is present (authoring container / GPU box with oracle/_ref)."""
+    from oracle import ref_ctypes
+    if not ref_ctypes.available():
+        pytest.skip("oracle/_ref/libsos_ref.so not built here")
+    for name in ["rayleigh_n25", "brdf_n13", "black_n9"]:
+        case = cases.make_case(name)
+        a = cases.run_cpu(ref_ctypes, case, 0)
+        b = cases.run_cpu(oracle, case, 0)
+        assert np.array_equal(a["ig_counts"], b["ig_counts"])
+        cases.compare_records(b["records"], a["records"], 1e-13, name)
+
+
+def test_aggregate_serial_semantics(oracle):
+    """SOS_AGGREGATE.F:372-488: weighted sum with zero padding of shorter bins, tau log-sum-exp."""
+    rng = np.random.default_rng(3)
+    nb, fmax, w = 5, 7, 9
+    rec = rng.normal(size=(nb, fmax, 3, w))
+    nf = np.array([7, 3, 5, 1, 6], dtype=np.int32)
+    for b in range(nb):
+        rec[b, nf[b]:] = 123.0  # garbage beyond nf must be ignored
+    aik = rng.dirichlet(np.ones(nb))
+    scal = np.abs(rng.normal(size=(nb, 7)))
+    out_rec, out_scal = oracle.aggregate(rec, nf, aik, scal)
+    exp = np.zeros((fmax, 3, w))
+    for b in range(nb):
+        exp[:nf[b]] += aik[b] * rec[b, :nf[b]]
+    assert out_rec.shape[0] == 7 and np.allclose(out_rec, exp, rtol=1e-13, atol=1e-15)
+    assert np.allclose(out_scal[:3], (aik[:, None] * scal[:, :3]).sum(0), rtol=1e-13)
+    assert np.allclose(out_scal[3:6], -np.log((aik[:, None] * np.exp(-scal[:, 3:6])).sum(0)), rtol=1e-12)
+
+
+def test_profile_rescale_matches_host(oracle, pkg):
+    """Host-side restatement of SOS.F:523-550 (synth.rescale_profile) == oracle's."""
+    S = pkg.synth
+    h, x, y, z = S.profile(30, k_abs=0.7)
+    for a_tronc, piz, piztr in [(0.0, 0.9, 0.9), (0.35, 0.93, 0.91)]:
+        h2, x2, y2, ib = S.rescale_profile(h, x, y, a_tronc, piz, piztr, 80)
+        h3, x3, y3, ib3 = oracle.profile_rescale(h, x, y, a_tronc, piz, piztr, 80)
+        assert ib == ib3 == 80
+        assert np.allclose(h2, h3, rtol=1e-15, atol=0) and np.allclose(x2, x3, rtol=1e-15, atol=0)
+        assert np.allclose(y2, y3, rtol=1e-15, atol=0)
+    _, x0, _, ib = S.rescale_profile(h, np.zeros_like(x), y, 0.0, 0.9, 0.9, 80)
+    assert ib == 2
