@@ -122,3 +122,43 @@ def aggregate(rec_bins, nf, aik, scal_bins):
                                    scal_bins.ctypes.data_as(C.c_void_p), out_rec.ctypes.data_as(C.c_void_p),
                                    out_scal.ctypes.data_as(C.c_void_p))
     return out_rec[:f], out_scal
+
+
+def sigma2(wind):
+    lib().sos_oracle_sigma2.restype = C.c_double
+    return lib().sos_oracle_sigma2(C.c_double(wind))
+
+
+def glitter(rmu, chr_, wind, ind, os_nb, os_ns, os_nm):
+    """SOS_GLITTER restatement: returns dict(rsurf float32[os_nb+1][9][N][N], il[npairs], e[npairs][os_nm+1],
+    coef[4][os_ns+1])."""
+    n = len(rmu)
+    npairs = n * (n + 1) // 2
+    a_mu, p_mu = _d(rmu)
+    a_ch, p_ch = _d(chr_)
+    out = np.zeros((os_nb + 1, 9, n, n), dtype=np.float32)
+    il = np.zeros(npairs, dtype=np.int32)
+    e = np.zeros((npairs, os_nm + 1))
+    coef = np.zeros((4, os_ns + 1))
+    lib().sos_oracle_glitter(C.c_int(n), p_mu, p_ch, C.c_double(wind), C.c_double(ind), C.c_int(os_nb), C.c_int(os_ns),
+                             C.c_int(os_nm), out.ctypes.data_as(C.c_void_p), il.ctypes.data_as(C.c_void_p),
+                             e.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p))
+    return dict(rsurf=out, il=il, e=e, coef=coef)
+
+
+def trphi(rmu, rec, tau, tauout, phi, *, igli=0, n0=1, wind=0.0, ind_surf=1.34, ifresnel=0, ipolar=1):
+    n = len(rmu)
+    w = 2 * n + 1
+    a_mu, p_mu = _d(rmu)
+    a_rec, p_rec = _d(rec)
+    outs = [np.zeros(w) for _ in range(4)]
+    lib().sos_oracle_trphi(C.c_int(n), p_mu, C.c_int(a_rec.shape[0]), p_rec, C.c_double(tau), C.c_double(tauout),
+                           C.c_double(phi), C.c_int(igli), C.c_int(n0), C.c_double(wind), C.c_double(ind_surf),
+                           C.c_int(ifresnel), C.c_int(ipolar), *[o.ctypes.data_as(C.c_void_p) for o in outs])
+    return outs
+
+
+def polar(xi, xq, xu):
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    lib().sos_oracle_polar(C.c_double(xi), C.c_double(xq), C.c_double(xu), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

@@ -231,3 +231,101 @@ def sos_noyaux(is_, rmu0, rmu, os_nb, alpha, beta, gamma, zeta):
     out = {k: m[sl, sl].copy() for k, m in zip(names, mats)}
     out.update({k: v[sl].copy() for k, v in zip(["XPL", "XRL", "XTL"], vec)})
     return out
+
+
+def write_fourier_file(path, rec):
+    """rec [F][3][W] (I,Q,U) -> FICOS/SOS_Result.bin layout: one record per order, Q,U,I (SOS_OS.F:1572)."""
+    rec = np.asarray(rec, dtype="<f8")
+    with open(path, "wb") as f:
+        for s in range(rec.shape[0]):
+            payload = np.concatenate([rec[s, 1], rec[s, 2], rec[s, 0]]).tobytes()
+            m = np.array([len(payload)], "<i4").tobytes()
+            f.write(m + payload + m)
+
+
+def sos_gsf(rmu, sig, os_nm):
+    """Reference SOS_GSF (SOS_GLITTER.F:451): returns (il[npairs], e[npairs][os_nm+1]) in (I1, I2<=I1) order."""
+    n = len(rmu)
+    tmp = tempfile.mkdtemp(prefix="sosref_")
+    try:
+        fic = os.path.join(tmp, "RES_GSF")
+        RMU = _dir_array(rmu, -1.0)
+        ier = C.c_int32(0)
+
+        def call():
+            lib().sos_gsf_(C.byref(C.c_int32(n)), _p(RMU), C.byref(C.c_double(sig)), C.byref(C.c_int32(os_nm)),
+                           _fstr(fic), C.byref(ier), C.c_size_t(LENFIC2))
+
+        _big_stack_call(call)
+        assert ier.value == 0
+        data = open(fic, "rb").read()
+        npairs = n * (n + 1) // 2
+        il = np.zeros(npairs, dtype=np.int32)
+        e = np.zeros((npairs, os_nm + 1))
+        off = 0
+        for p in range(npairs):
+            nbytes = int(np.frombuffer(data, "<i4", 1, off)[0])
+            i1, i2, l = np.frombuffer(data, "<i4", 3, off + 4)
+            il[p] = l
+            e[p, :l + 1] = np.frombuffer(data, "<f8", l + 1, off + 16)
+            off += 8 + nbytes
+        return il, e
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sos_glitter(rmu, chr_, wind, ind, os_nb, os_ns, os_nm):
+    """Reference SOS_GLITTER (SOS_GLITTER.F:229): returns the GLITTER file content as float32
+    [os_nb+1][9][N][N] (record order, [J][I])."""
+    n = len(rmu)
+    tmp = tempfile.mkdtemp(prefix="sosref_")
+    try:
+        f1, f2, f3, f4 = (os.path.join(tmp, x) for x in ("RES_GSF", "RES_FRESNEL", "RES_MAT_REFLEX", "GLITTER"))
+        RMU = _dir_array(rmu, -1.0)
+        CHR = _dir_array(chr_, 1.0)
+        ier = C.c_int32(0)
+        i4 = lambda v: C.byref(C.c_int32(v))
+
+        def call():
+            lib().sos_glitter_(i4(n), _p(RMU), _p(CHR), C.byref(C.c_double(wind)), C.byref(C.c_double(ind)),
+                               i4(os_nb), i4(os_ns), i4(os_nm), _fstr(f1), _fstr(f2), _fstr(f3), _fstr(f4),
+                               i4(0), C.byref(ier), C.c_size_t(LENFIC2), C.c_size_t(LENFIC2), C.c_size_t(LENFIC2),
+                               C.c_size_t(LENFIC2))
+
+        _big_stack_call(call)
+        assert ier.value == 0
+        recs = read_fortran_records(f4, "<f4")
+        return np.array(recs).reshape(os_nb + 1, 9, n, n)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sos_trphi(rmu, rec, tau, tauout, phi, *, igli=0, n0=1, wind=0.0, ind_surf=1.34, ifresnel=0, ipolar=1):
+    """Reference SOS_TRPHI (SOS_TRPHI.F:749) for one azimuth phi (radians); land BRDF/BPDF terms off.
+    Returns xit, xqt, xut, angdiff as (2N+1) arrays (slot 0 zeroed)."""
+    n = len(rmu)
+    tmp = tempfile.mkdtemp(prefix="sosref_")
+    try:
+        fic = os.path.join(tmp, "RESULT.bin")
+        write_fourier_file(fic, rec)
+        RMU = _dir_array(rmu, -1.0)
+        outs = [np.zeros(2 * NBMU_MAX + 1) for _ in range(4)]
+        ier = C.c_int32(0)
+        i4 = lambda v: C.byref(C.c_int32(v))
+        f8 = lambda v: C.byref(C.c_double(v))
+
+        def call():
+            lib().sos_trphi_(_fstr(fic), i4(n), _p(RMU), f8(tau), f8(tauout), f8(phi), i4(igli), i4(n0), f8(wind),
+                             f8(ind_surf), i4(ifresnel), i4(0), f8(0.), f8(0.), f8(0.), i4(0), i4(0), i4(0), f8(0.),
+                             f8(0.), i4(0), f8(0.), i4(ipolar), *[_p(o) for o in outs], C.byref(ier),
+                             C.c_size_t(LENFIC2))
+
+        _big_stack_call(call)
+        assert ier.value == 0
+        sl = slice(NBMU_MAX - n, NBMU_MAX + n + 1)
+        res = [o[sl].copy() for o in outs]
+        for r in res:
+            r[n] = 0.0
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

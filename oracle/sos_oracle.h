@@ -60,6 +60,25 @@ int sos_oracle_aggregate(int nb, int fmax, int w, const int *nf, const double *a
                          const double *rec_bins, const double *scal_bins,
                          double *out_rec, double *out_scal);
 
+/* ---- Cox-Munk glitter (sos_glitter_oracle.c) ---- */
+/* SIG = .003 + .00512*WIND with the REAL*4 literals of SOS_GLITTER.F:300 */
+double sos_oracle_sigma2(double wind);
+/* SOS_GSF for one pair (SOS_GLITTER.F:523-683): e[0..os_nm], returns IL */
+int sos_oracle_gsf_pair(double mu1, double mu2, double sig, int os_nm, double *e);
+/* SOS_MAT_FRESNEL incl. the 4(E15.8) round trip (SOS_SURFACE.F:1235-1603) */
+void sos_oracle_mat_fresnel(int n, const double *mu, const double *chr, double ind, int os_ns,
+                            double *alpha, double *beta, double *gamma, double *zeta);
+/* SOS_GLITTER end to end (SOS_GLITTER.F:229-371): out REAL*4 [os_nb+1][9][N][N] in GLITTER-file order;
+ * optional il_out[npairs], e_out[npairs][os_nm+1], coef_out[4][os_ns+1] */
+int sos_oracle_glitter(int n, const double *mu, const double *chr, double wind, double ind,
+                       int os_nb, int os_ns, int os_nm, float *out, int *il_out, double *e_out, double *coef_out);
+
+/* ---- azimuth recomposition (sos_trphi_oracle.c) ---- */
+void sos_oracle_polar(double xi, double xq, double xu, double *xan, double *tpol, double *lpol);
+void sos_oracle_trphi(int n, const double *mu, int nf, const double *rec, double tau, double tauout, double phi,
+                      int igli, int n0, double wind, double ind_surf, int ifresnel, int ipolar,
+                      double *xit, double *xqt, double *xut, double *angdiff);
+
 #ifdef __cplusplus
 }
 #endif
