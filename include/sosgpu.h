@@ -111,6 +111,33 @@ int  sosgpu_aggregate(sosgpu_ctx *cx, int nseg, const int32_t *d_seg, const doub
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
                       double *d_out_rec, double *d_out_scal, void *stream);
 
+/* Replaces SOS_GLITTER (SOS_GLITTER.F:229-371: SOS_GSF + SOS_MAT_FRESNEL + SOS_MAT_REFLEXION +
+ * SOS_MISE_FORMAT, no temporary files).  Host inputs mu[n], chr[n] (Gauss weights), wind (m/s), ind (water
+ * refractive index), orders OS_NB, OS_NS, OS_NM (>= OS_NB+OS_NS).  Device outputs:
+ *  d_rsurf[os_nb+1][9][N][N]  REAL*4 matrices in GLITTER-file record order (feed to
+ *                             sosgpu_set_surface_matrices with imat_surf = 1)
+ *  d_il[N(N+1)/2]             series length IL of each angle pair (I1 = 1..N, I2 = 1..I1), SOS_GLITTER.F:676
+ *  d_e[N(N+1)/2][os_nm+1]     Fourier coefficients E(0:IL) of the facet function, zero beyond IL
+ * Synchronous with respect to the host arrays; kernels run on `stream`. */
+int  sosgpu_glitter(int device, int n, const double *mu, const double *chr, double wind, double ind,
+                    int os_nb, int os_ns, int os_nm, float *d_rsurf, int32_t *d_il, double *d_e, void *stream);
+/* Host helper used by sosgpu_glitter, exposed for parity tests: SOS_MAT_FRESNEL (SOS_SURFACE.F:1235-1603)
+ * including the 4(E15.8) text round trip; out[4][os_ns+1] = alpha, beta, gamma, zeta. */
+int  sosgpu_mat_fresnel_host(int n, const double *mu, const double *chr, double ind, int os_ns, double *out);
+
+/* Replaces SOS_TRPHI (SOS_TRPHI.F:749-1243) + SOS_POLAR (:1843) for nphi azimuths at once.
+ *  nf           number of Fourier orders in d_rec (records beyond are ignored)
+ *  d_rec[nf][3][W]  aggregated Fourier records (sosgpu_aggregate output, after the cross-GPU reduce)
+ *  tau, tauout  total (truncated) optical depth and optical depth of the output level (TTOT_TRONC, TAUOUT)
+ *  d_phi[nphi]  azimuths in radians
+ *  igli         1: add the directly reflected Cox-Munk glint (needs wind); the flat-sea sun glint is added
+ *               when the context has ifresnel = 1
+ *  d_out[nphi][7][W]: XIT, XQT, XUT, ANGDIFF (deg), polarisation angle, rate (%), polarised radiance;
+ *               slot jj = 0 is zero.
+ * Land BRDF/BPDF direct terms (IROUJEAN, IRONDEAUX, IBREON, INADAL, IMAIGNAN) are not implemented. */
+int  sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
+                  const double *d_phi, int igli, double wind, double *d_out, void *stream);
+
 /* Scratch requirements (bytes) of the context on its device, for memory planning. */
 size_t sosgpu_ctx_bytes(const sosgpu_ctx *cx);
 

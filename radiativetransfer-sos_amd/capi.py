@@ -14,7 +14,7 @@ EXPORTS = [
     "sosgpu_strerror", "sosgpu_last_hip_error", "sosgpu_device_count", "sosgpu_version",
     "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
-    "sosgpu_os_flops", "sosgpu_last_solve_ms",
+    "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
 ]
 
 
@@ -70,6 +70,12 @@ def lib():
         L.sosgpu_os_flops.argtypes = [vp, i32, vp, vp, vp, C.POINTER(dbl)]
         L.sosgpu_last_solve_ms.restype = i32
         L.sosgpu_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.sosgpu_glitter.restype = i32
+        L.sosgpu_glitter.argtypes = [i32, i32, vp, vp, dbl, dbl, i32, i32, i32, vp, vp, vp, vp]
+        L.sosgpu_mat_fresnel_host.restype = i32
+        L.sosgpu_mat_fresnel_host.argtypes = [i32, vp, vp, dbl, i32, vp]
+        L.sosgpu_trphi.restype = i32
+        L.sosgpu_trphi.argtypes = [vp, i32, vp, dbl, dbl, i32, vp, i32, dbl, vp, vp]
         _lib = L
     return _lib
 

@@ -5,6 +5,7 @@
 #include "sos_common.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct sosgpu_ctx {
     bool timed;
     hipStream_t last_stream;
     int nt_max_hint;
+    double ind_surf;
 };
 
 extern "C" const char *sosgpu_version(void) { return "sosgpu 0.1 (gfx950)"; }
@@ -82,6 +84,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->bytes = 0;
     cx->timed = false;
     cx->last_stream = nullptr;
+    cx->ind_surf = wv->ind_surf;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -263,6 +266,134 @@ extern "C" int sosgpu_aggregate(sosgpu_ctx *cx, int nseg, const int32_t *d_seg, 
         return SOSGPU_E_ARG;
     HIPCHK(hipSetDevice(cx->device));
     launch_aggregate(cx->d, nseg, d_seg, d_aik, d_rec, d_norders, d_flux, d_scal, d_out_rec, d_out_scal, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cox-Munk glitter: host part = SOS_MAT_FRESNEL (SOS_SURFACE.F:1235-1603), O(N*OS_NS) flops and a
+// 4(E15.8) text round trip (:1552 write, :1822 read) that has to be reproduced digit for digit.
+// ---------------------------------------------------------------------------------------------
+static double through_e15_8(double x)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.7E", x);   // 8 significant digits, round to nearest = Fortran E15.8
+    return strtod(buf, nullptr);
+}
+
+static double sigma2_of_wind(double wind) { return (double)0.003f + (double)0.00512f * wind; }   // SOS_GLITTER.F:300
+
+extern "C" int sosgpu_mat_fresnel_host(int n, const double *mu, const double *chr, double ind, int os_ns, double *out)
+{
+    if (n < 1 || os_ns < 2 || !mu || !chr || !out) return SOSGPU_E_ARG;
+    const int K = os_ns + 1;
+    double *alpha = out, *beta = out + K, *gamma = out + 2 * K, *zeta = out + 3 * K;
+    std::vector<double> delta(K, 0.), pl(os_ns + 3, 0.), pol(os_ns + 2, 0.), r11(2 * n), r12(2 * n), r33(2 * n), xm(2 * n), xw(2 * n);
+    for (int k = 0; k < 4 * K; k++) out[k] = 0.;
+    // directions in the reference loop order J = -N..-1, 1..N (SOS_SURFACE.F:1346)
+    for (int q = 0; q < 2 * n; q++) {
+        const int j = q < n ? -(n - q) : q - n + 1;
+        xm[q] = j > 0 ? mu[j - 1] : -mu[-j - 1];
+        xw[q] = j > 0 ? chr[j - 1] : chr[-j - 1];
+        double c = sqrt(.5 * (1 + xm[q]));
+        const double a = sqrt(ind * ind - 1.0 + c * c);
+        const double b = ind * ind * c;
+        const double rl = -(b - a) / (b + a);
+        const double rr = (c - a) / (c + a);
+        r11[q] = .5 * (rl * rl + rr * rr);
+        r12[q] = .5 * (rl * rl - rr * rr);
+        r33[q] = rl * rr;
+    }
+    double *PL = pl.data() + 1;   // PL(-1:OS_NS+1)
+    for (int q = 0; q < 2 * n; q++) {            // :1387-1400
+        const double x = r11[q] * xw[q], xrmu = xm[q];
+        PL[-1] = 0.; PL[0] = 1.;
+        for (int k = 0; k <= os_ns; k++) {
+            PL[k + 1] = ((2 * k + 1.) * xrmu * PL[k] - k * PL[k - 1]) / (k + 1.);
+            beta[k] = beta[k] + x * PL[k];
+        }
+    }
+    for (int k = 0; k <= os_ns; k++) beta[k] = (2 * k + 1) * beta[k] * .5;
+    for (int q = 0; q < 2 * n; q++) {            // :1433-1456
+        const double xxx = xw[q] * r12[q], xx = xw[q] * r33[q], xrmu = xm[q];
+        pol[0] = 0.; pol[1] = 0.;
+        PL[-1] = 0.; PL[0] = 1.;
+        pol[2] = 3. * (1. - xrmu * xrmu) / 2. / sqrt(6.0);
+        for (int k = 2; k <= os_ns; k++) {
+            const double d = (2. * k + 1.) / sqrt(1.0 * (k + 3.) * (k - 1.));
+            const double e = sqrt(1.0 * (k + 2.) * (k - 2.)) / (2. * k + 1.);
+            pol[k + 1] = d * (xrmu * pol[k] - e * pol[k - 1]);
+            gamma[k] = gamma[k] + xxx * pol[k];
+        }
+        for (int k = 0; k <= os_ns; k++) {
+            PL[k + 1] = ((2. * k + 1.) * xrmu * PL[k] - k * PL[k - 1]) / (k + 1.);
+            delta[k] = delta[k] + xx * PL[k];
+        }
+    }
+    for (int k = 0; k <= os_ns; k++) {
+        delta[k] = delta[k] * (2. * k + 1.) * .5;
+        gamma[k] = gamma[k] * (2. * k + 1.) * .5;
+    }
+    for (int i = 2; i <= os_ns; i++) {           // :1521-1546 ; CO1, CO2 are REAL*4 expressions
+        const float co1f = 4 * (2 * i + 1.f) / (float)i / (i - 1.f) / (i + 1.f) / (i + 2.f);
+        const float co2f = i * (i - 1.f) / ((i + 1.f) * (i + 2.f));
+        const double co1 = co1f;
+        double co2 = co2f;
+        const double co3 = co2 * delta[i];
+        co2 = co2 * beta[i];
+        const int nn = (int)(i * .5f), mm = (int)((i - 1) * .5f);
+        double som1 = 0., som2 = 0., som3 = 0., som4 = 0.;
+        for (int j = 1; j <= nn; j++) {
+            const double x2 = (double)((i - 1.f) * (i - 1.f) - 3.f * (2 * j - 1.f) * (i - j));
+            som1 = som1 + x2 * beta[i - 2 * j];
+            som2 = som2 + x2 * delta[i - 2 * j];
+        }
+        for (int j = 0; j <= mm; j++) {
+            const double x2 = (double)((i - 1.f) * (i - 1.f) - 3.f * j * (2 * i - 2 * j - 1.f));
+            som3 = som3 + x2 * beta[i - 2 * j - 1];
+            som4 = som4 + x2 * delta[i - 2 * j - 1];
+        }
+        zeta[i] = co3 - co1 * (som2 - som3);
+        alpha[i] = co2 - co1 * (som1 - som4);
+    }
+    for (int k = 0; k < 4 * K; k++) out[k] = through_e15_8(out[k]);
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_glitter(int device, int n, const double *mu, const double *chr, double wind, double ind,
+                              int os_nb, int os_ns, int os_nm, float *d_rsurf, int32_t *d_il, double *d_e, void *stream)
+{
+    if (n < 1 || n > 85 || !mu || !chr || !d_rsurf || !d_il || !d_e) return SOSGPU_E_ARG;
+    if (os_nb < 0 || os_ns < 2 || os_nm < os_nb + os_ns || os_nm > 2000) return SOSGPU_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    std::vector<double> fcoef((size_t)4 * (os_ns + 1));
+    int rc = sosgpu_mat_fresnel_host(n, mu, chr, ind, os_ns, fcoef.data());
+    if (rc) return rc;
+    double *d_buf = nullptr;
+    const size_t cnt = (size_t)n + fcoef.size();
+    HIPCHK(hipMalloc((void **)&d_buf, cnt * sizeof(double)));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpy(d_buf, mu, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_buf + n, fcoef.data(), fcoef.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_glitter(n, d_buf, sigma2_of_wind(wind), os_nb, os_ns, os_nm, d_buf + n, d_il, d_e, d_rsurf, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_buf);
+    HIPCHK(e);
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
+                            const double *d_phi, int igli, double wind, double *d_out, void *stream)
+{
+    if (!cx || nf < 1 || nf > cx->d.smax + 1 || !d_rec || nphi < 1 || !d_phi || !d_out) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(cx->device));
+    launch_trphi(cx->d, nf, d_rec, tau, tauout, nphi, d_phi, igli, sigma2_of_wind(wind), cx->ind_surf, d_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return SOSGPU_OK;
 }

@@ -13,3 +13,8 @@ int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes);
 void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
                       double *d_out_rec, double *d_out_scal, hipStream_t st);
+
+void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
+                    int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st);
+void launch_trphi(const SosDev &cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
+                  const double *d_phi, int igli, double sigma2, double ind_surf, double *d_out, hipStream_t st);

@@ -168,6 +168,18 @@ class SosContext:
                                                _ptr(o_rec), _ptr(o_scal), self._stream()), "sosgpu_aggregate")
         return o_rec, o_scal
 
+    def trphi(self, rec, nf, tau, tauout, phis_rad, igli=0, wind=0.0):
+        """SOS_TRPHI + SOS_POLAR for a list of azimuths (radians).  rec: device tensor [>=nf][3][W]
+        (aggregated records).  Returns a device tensor [nphi][7][W]: XIT, XQT, XUT, ANGDIFF, polarisation
+        angle, polarisation rate, polarised radiance."""
+        d = self.device
+        phis = _dev_f64(np.atleast_1d(np.asarray(phis_rad, dtype=np.float64)), d)
+        rec = rec.to(device=d, dtype=torch.float64).contiguous()
+        out = torch.empty((phis.numel(), 7, self.w), dtype=torch.float64, device=d)
+        capi.check(capi.lib().sosgpu_trphi(self._h, int(nf), _ptr(rec), float(tau), float(tauout), phis.numel(),
+                                           _ptr(phis), int(igli), float(wind), _ptr(out), self._stream()), "sosgpu_trphi")
+        return out
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             torch.cuda.synchronize(self.device)

@@ -49,6 +49,40 @@ def gen_noyaux():
     print("noyaux ok")
 
 
+def gen_glitter():
+    S = cases.S
+    mu, w, n0 = S.gauss_angles(12, 35.0)
+    d = dict(mu=mu, chr=w)
+    from oracle import oracle_ctypes as O
+    for wind in (2.0, 7.0):
+        rs = R.sos_glitter(mu, w, wind, 1.34, 24, 24, 48)
+        il, e = R.sos_gsf(mu, O.sigma2(wind), 48)
+        d["rsurf_w%d" % wind], d["il_w%d" % wind], d["e_w%d" % wind] = rs, il, e
+    np.savez_compressed(os.path.join(HERE, "glitter_n13.npz"), **d)
+    print("glitter ok")
+
+
+def gen_trphi():
+    S = cases.S
+    mu, w, n0 = S.gauss_angles(12, 35.0)
+    rng = np.random.default_rng(0)
+    rec = rng.normal(size=(9, 3, 2 * len(mu) + 1)) * (0.5 ** np.arange(9))[:, None, None]
+    rec[:, 0] = np.abs(rec[:, 0]) + 0.1
+    rec[:, :, len(mu)] = 0.0
+    phis = np.array([0.0, 0.7, np.pi, np.pi + 0.3, 2.0, 2 * np.pi - 0.2])
+    cfgs = [dict(igli=0, wind=0.0, ifresnel=0, ipolar=1), dict(igli=1, wind=7.0, ifresnel=0, ipolar=1),
+            dict(igli=0, wind=0.0, ifresnel=1, ipolar=1), dict(igli=1, wind=2.0, ifresnel=0, ipolar=0)]
+    d = dict(mu=mu, n0=n0, rec=rec, phis=phis, ncases=len(cfgs))
+    for i, c in enumerate(cfgs):
+        for k, v in c.items():
+            d["%s%d" % (k, i)] = v
+        d["out%d" % i] = np.array([R.sos_trphi(mu, rec, 0.4, 0.05, float(p), n0=n0, **c) for p in phis])
+    np.savez_compressed(os.path.join(HERE, "trphi_n13.npz"), **d)
+    print("trphi ok")
+
+
 if __name__ == "__main__":
+    gen_glitter()
+    gen_trphi()
     gen_noyaux()
     gen_sos_os()
