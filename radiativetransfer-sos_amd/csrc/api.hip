@@ -91,6 +91,8 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     d.kp = sos_round_up(6 * N, 8); d.ks2 = d.kp / 8;
     const int rt = (6 * N + 15) / 16;
     d.rtp = 4 * ((rt + 3) / 4);
+    d.kh = sos_round_up(3 * N, 8); d.ks2h = d.kh / 8;
+    d.rtph = 4 * (((d.kh / 16 + ((d.kh % 16) ? 1 : 0)) + 3) / 4);
     d.os_nb = B; d.smax = iborm_max;
     d.n0 = wv->n0; d.imat_surf = wv->imat_surf == 1; d.ifresnel = wv->ifresnel == 1 ? 1 : 0;
     d.igmax = wv->igmax; d.ipolar = wv->ipolar ? 1 : 0;
@@ -138,7 +140,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     UP(d.coef, coef.data(), coef.size())
     UP(d.fres, fres.data(), fres.size())
 #undef UP
-    const size_t per = (size_t)d.rtp * d.ks2 * 128;
+    const size_t per = (size_t)2 * d.rtph * d.ks2h * 128;
     if ((rc = dev_alloc(cx, &d.prt, (size_t)(d.smax + 1) * 3 * (B + 1) * d.w)) ||
         (rc = dev_alloc(cx, &d.mp_aer, (size_t)(d.smax + 1) * per)) ||
         (rc = dev_alloc(cx, &d.mp_ray, (size_t)3 * per)) ||

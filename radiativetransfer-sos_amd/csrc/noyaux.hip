@@ -131,47 +131,53 @@ __device__ inline double ktab(const SosDev &cx, int s, int X, int a, int b)
     return sum;
 }
 
-// Source operator element M[(co,so,k)][(ci,si,j)] of SOS_FSOURCE_ORDREIG (SOS_OS.F:2894-2915), with the
-// Gauss weight and the final 1/2 folded in.  Table (rel = +1 if so == si else -1):
-//   I<-I  BP(j,rel k)      I<-Q  GR(k,rel j)        I<-U  -so GT(k,rel j)
-//   Q<-I  GR(j,rel k)      Q<-Q  ARR(j,rel k)       Q<-U  -si ART(j,rel k)
-//   U<-I  -si GT(j,rel k)  U<-Q  -so ART(k,rel j)   U<-U  ATT(j,rel k)
+// Half-system operator element (parity decomposition, sos_common.h).  sg = +1 for system A, -1 for B;
+// plus(X,a,b) = X(a,b) + sg X(a,-b), minus(X,a,b) = X(a,b) - sg X(a,-b); rows/cols kk = c*N + (k-1):
+//   I<-I  plus(BP,j,k)    I<-Q  plus(GR,k,j)     I<-U  -minus(GT,k,j)
+//   Q<-I  plus(GR,j,k)    Q<-Q  plus(ARR,j,k)    Q<-U  -plus(ART,j,k)
+//   U<-I  -minus(GT,j,k)  U<-Q  -plus(ART,k,j)   U<-U  minus(ATT,j,k)
+// times w_j/4 (the reference's Gauss weight and final 1/2, and the 1/2 of the recombination).
 template <bool RAY>
-__device__ inline double op_element(const SosDev &cx, int s, int row, int col)
+__device__ inline double half_element(const SosDev &cx, int s, int sys, int row, int col)
 {
     const int N = cx.n;
-    const int co = row / (2 * N), dor = row % (2 * N), ci = col / (2 * N), dic = col % (2 * N);
-    const int so = dor < N ? 1 : -1, k = dor < N ? dor + 1 : dor - N + 1;
-    const int si = dic < N ? 1 : -1, j = dic < N ? dic + 1 : dic - N + 1;
-    const int rel = so * si;
-    double v;
+    const int co = row / N, k = row % N + 1, ci = col / N, j = col % N + 1;
+    const double sg = sys ? -1. : 1.;
+    int X, a, b;
+    bool mns = false, neg = false;
     switch (co * 3 + ci) {
-    case 0: v = ktab<RAY>(cx, s, 0, j, rel * k); break;
-    case 1: v = ktab<RAY>(cx, s, 1, k, rel * j); break;
-    case 2: v = -so * ktab<RAY>(cx, s, 2, k, rel * j); break;
-    case 3: v = ktab<RAY>(cx, s, 1, j, rel * k); break;
-    case 4: v = ktab<RAY>(cx, s, 3, j, rel * k); break;
-    case 5: v = -si * ktab<RAY>(cx, s, 4, j, rel * k); break;
-    case 6: v = -si * ktab<RAY>(cx, s, 2, j, rel * k); break;
-    case 7: v = -so * ktab<RAY>(cx, s, 4, k, rel * j); break;
-    default: v = ktab<RAY>(cx, s, 5, j, rel * k); break;
+    case 0: X = 0; a = j; b = k; break;
+    case 1: X = 1; a = k; b = j; break;
+    case 2: X = 2; a = k; b = j; mns = true; neg = true; break;
+    case 3: X = 1; a = j; b = k; break;
+    case 4: X = 3; a = j; b = k; break;
+    case 5: X = 4; a = j; b = k; neg = true; break;
+    case 6: X = 2; a = j; b = k; mns = true; neg = true; break;
+    case 7: X = 4; a = k; b = j; neg = true; break;
+    default: X = 5; a = j; b = k; mns = true; break;
     }
-    return 0.5 * cx.ga[j - 1] * v;
+    const double same = ktab<RAY>(cx, s, X, a, b), opp = ktab<RAY>(cx, s, X, a, -b);
+    double v = mns ? (same - sg * opp) : (same + sg * opp);
+    if (neg) v = -v;
+    return 0.25 * cx.ga[j - 1] * v;
 }
 
 __global__ void k_pack(SosDev cx)
 {
     const int s = blockIdx.y;
-    const size_t per = (size_t)cx.rtp * cx.ks2 * 128;
+    const size_t per = (size_t)cx.rtph * cx.ks2h * 128;     // one system
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= per) return;
-    const int e2 = e & 1, lane = (e >> 1) & 63;
-    const int m = (int)((e >> 7) % cx.ks2), rt = (int)((e >> 7) / cx.ks2);
+    if (e >= 2 * per) return;
+    const int sys = e >= per;
+    const size_t q = e - (size_t)sys * per;
+    const int e2 = q & 1, lane = (q >> 1) & 63;
+    const int m = (int)((q >> 7) % cx.ks2h), rt = (int)((q >> 7) / cx.ks2h);
     const int row = rt * 16 + (lane & 15);
     const int col = 8 * m + 2 * (lane >> 4) + e2;
-    const bool in = row < cx.r6 && col < cx.r6;
-    cx.mp_aer[(size_t)s * per + e] = in ? op_element<false>(cx, s, row, col) : 0.;
-    if (s <= 2) cx.mp_ray[(size_t)s * per + e] = in ? op_element<true>(cx, s, row, col) : 0.;
+    const int H = 3 * cx.n;
+    const bool in = row < H && col < H;
+    cx.mp_aer[(size_t)s * 2 * per + e] = in ? half_element<false>(cx, s, sys, row, col) : 0.;
+    if (s <= 2) cx.mp_ray[(size_t)s * 2 * per + e] = in ? half_element<true>(cx, s, sys, row, col) : 0.;
 }
 
 // Order-1 source vectors, one per state row r = (c, +-k):
@@ -232,7 +238,7 @@ void launch_noyaux(const SosDev &cx, hipStream_t st)
 {
     const int S = cx.smax + 1;
     k_gsf<<<S, 128, 0, st>>>(cx);
-    const size_t per = (size_t)cx.rtp * cx.ks2 * 128;
+    const size_t per = (size_t)2 * cx.rtph * cx.ks2h * 128;
     dim3 g((unsigned)((per + 255) / 256), S);
     k_pack<<<g, 256, 0, st>>>(cx);
     k_sv<<<S, sos_round_up(cx.kp, 64), 0, st>>>(cx);

@@ -12,15 +12,22 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // The reference keeps three fields X(0:NT,-N:N) (SOS_OS.F:447-449); this is the same data with the
 // unused jj = 0 column dropped.
 //
-// Packed operator layout (A operand of v_mfma_f64_16x16x4_f64, one f64 per lane):
-//   mp[((rt*KS2 + m)*64 + lane)*2 + e] = M[rt*16 + (lane&15)][8m + 2*(lane>>4) + e]
+// Parity decomposition of the source operator (SOS_FSOURCE_ORDREIG, SOS_OS.F:2894-2915).  With
+// X^A = X(+mu) + g_c X(-mu), X^B = X(+mu) - g_c X(-mu), g = (+1,+1,-1) for (I,Q,U), the 6N x 6N operator
+// splits into two independent 3N x 3N systems (A couples I^e,Q^e,U^o; B couples I^o,Q^o,U^e):
+//   E^A = M^A X^A, E^B = M^B X^B,   S(+mu) = E^A + E^B,  S(-mu) = g_c (E^A - E^B)
+// which halves the matrix-core work and the operator stream.  Half-system index kk = c*N + (k-1).
+//
+// Packed operator layout (A operand of v_mfma_f64_16x16x4_f64, one f64 per lane), per order s and system:
+//   mp[(((s*2 + sys)*RTPH + rt)*KS2H + m)*128 + lane*2 + e] = M^sys[rt*16 + (lane&15)][8m + 2*(lane>>4) + e]
 // i.e. a wave reads 1 KiB contiguous per pair of k-steps (global_load_dwordx4 per lane) and MFMA k-step
 // (m,e) contracts the K indices {8m + 2q + e : q = 0..3}; the B operand is read from LDS with the same
 // K permutation (one ds_read_b128 per lane per pair of k-steps).
 
 struct SosDev {                 // per-wavelength device context, passed by value to the kernels
     int n, w, r6;               // N, 2N+1, 6N
-    int kp, ks2, rtp;           // padded K (multiple of 8), kp/8, padded row tiles (4*RTW)
+    int kp, ks2, rtp;           // order-1 vector stride (6N padded to 8); legacy full-operator sizes (unused by the solver)
+    int kh, ks2h, rtph;         // half system: 3N padded to 8, kh/8, padded row tiles per system (4*RTWH)
     int os_nb, smax;            // OS_NB, iborm_max
     int n0, imat_surf, ifresnel, igmax, ipolar;
     double mus;                 // cos(solar zenith) = mu[n0-1]; the reference's TAB = -mus

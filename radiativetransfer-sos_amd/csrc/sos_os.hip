@@ -73,64 +73,84 @@ __device__ __forceinline__ double queue_term(double d, double g)
     return (d == 0.) ? 0. : g / (1 - g / d);
 }
 
-// Source contraction: acc += sum over passes of Mp_pass * (scale_pass o field).  Pass 0 = aerosol
-// operator with XDEL, pass 1 = molecular operator with YDEL (s <= 2 only).  One copy of the MFMA loop.
-template <int RTW, int CT>
-__device__ __forceinline__ void gemm_source(v4d (&acc)[RTW][CT], const double *__restrict__ mp0,
-                                            const double *__restrict__ mp1, int pass_lo, int pass_hi, int ks2,
-                                            const double *fld, int CS, const double *scale0, const double *scale1,
-                                            int lane, int wv)
+// Source contraction in the parity-decomposed form (sos_common.h): for both half systems
+//   acc[sys] += sum over passes of M^sys_pass * (scale_pass o X^sys),  X^A = X+ + g X-,  X^B = X+ - g X-
+// Pass 0 = aerosol operator with XDEL, pass 1 = molecular operator with YDEL (s <= 2 only).
+// LDS field rows: [0,KH) = X(+mu) in half-system order kk = c*N + (k-1), [KH,2KH) = X(-mu).
+// Each wave owns RTWH row tiles of BOTH systems (so S(+mu) = E^A + E^B and S(-mu) = g (E^A - E^B) are
+// formed in registers) x CT column tiles; one copy of the MFMA loop.
+template <int RTWH, int CT>
+__device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp0,
+                                            const double *__restrict__ mp1, int pass_lo, int pass_hi, int ks2h, int rtph,
+                                            int n2, const double *fld, int CS, int KH, const double *scale0,
+                                            const double *scale1, int lane, int wv)
 {
-    const size_t rts = (size_t)ks2 * 64;     // v2d stride between row tiles
+    const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
+    const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
     const double *bp[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) bp[ct] = fld + (size_t)(ct * 16 + (lane & 15)) * CS + 2 * (lane >> 4);
 #pragma unroll 1
     for (int pass = pass_lo; pass < pass_hi; pass++) {
-        const v2d *ap = reinterpret_cast<const v2d *>(pass ? mp1 : mp0) + ((size_t)(wv * RTW) * ks2) * 64 + lane;
+        const v2d *ap = reinterpret_cast<const v2d *>(pass ? mp1 : mp0) + ((size_t)(wv * RTWH) * ks2h) * 64 + lane;
         const double *scale = pass ? scale1 : scale0;
         double sc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) sc[ct] = scale[ct * 16 + (lane & 15)];
-        v2d a_cur[RTW], a_nxt[RTW];
+        v2d a_cur[2][RTWH], a_nxt[2][RTWH];
 #pragma unroll
-        for (int rt = 0; rt < RTW; rt++) { a_cur[rt] = ap[rt * rts]; a_nxt[rt] = a_cur[rt]; }
+        for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+            for (int rt = 0; rt < RTWH; rt++) { a_cur[sy][rt] = ap[sy * sys_stride + rt * rts]; a_nxt[sy][rt] = a_cur[sy][rt]; }
 #pragma unroll 1
-        for (int m = 0; m < ks2; m++) {
-            if (m + 1 < ks2) {
+        for (int m = 0; m < ks2h; m++) {
+            if (m + 1 < ks2h) {
 #pragma unroll
-                for (int rt = 0; rt < RTW; rt++) a_nxt[rt] = ap[rt * rts + (size_t)(m + 1) * 64];
+                for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                    for (int rt = 0; rt < RTWH; rt++) a_nxt[sy][rt] = ap[sy * sys_stride + rt * rts + (size_t)(m + 1) * 64];
             }
-            v2d bb[CT];
+            // g = +1 for I,Q rows (kk < 2N), -1 for U rows; the two K indices of this lane are 8m+2q and 8m+2q+1
+            const int kk0 = 8 * m + 2 * (lane >> 4);
+            const double g0 = (kk0 < n2) ? 1. : -1., g1 = (kk0 + 1 < n2) ? 1. : -1.;
+            v2d ba[CT], bb[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                bb[ct] = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
-                bb[ct].x *= sc[ct];
-                bb[ct].y *= sc[ct];
+                const v2d xp = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
+                const v2d xm = *reinterpret_cast<const v2d *>(bp[ct] + KH + 8 * m);
+                const double m0 = g0 * xm.x, m1 = g1 * xm.y;
+                ba[ct].x = (xp.x + m0) * sc[ct]; ba[ct].y = (xp.y + m1) * sc[ct];
+                bb[ct].x = (xp.x - m0) * sc[ct]; bb[ct].y = (xp.y - m1) * sc[ct];
             }
 #pragma unroll
-            for (int rt = 0; rt < RTW; rt++)
+            for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
-                for (int ct = 0; ct < CT; ct++)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[rt].x, bb[ct].x, acc[rt][ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ct++) {
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
+                }
 #pragma unroll
-            for (int rt = 0; rt < RTW; rt++)
+            for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
-                for (int ct = 0; ct < CT; ct++)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[rt].y, bb[ct].y, acc[rt][ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ct++) {
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
+                }
 #pragma unroll
-            for (int rt = 0; rt < RTW; rt++) a_cur[rt] = a_nxt[rt];
+            for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                for (int rt = 0; rt < RTWH; rt++) a_cur[sy][rt] = a_nxt[sy][rt];
         }
     }
 }
 
-template <int RTW, int CT>
-__global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
+template <int RTWH, int CT>
+__global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
     constexpr int COLS = 16 * CT;
-    const int N = cx.n, R6 = cx.r6, KP = cx.kp, CS = cx.kp + 2, W = cx.w;
-    double *fld = smem;                    // [COLS][CS]   field / source, [level][row]
+    const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
+    double *fld = smem;                    // [COLS][CS]   field / source, [level][+mu rows | -mu rows]
     double *att = fld + COLS * CS;         // [COLS][N]    exp(-dtau_i/mu_j), layer i = levels i..i+1
     double *dtau = att + COLS * N;         // [COLS] each:
     double *idtau = dtau + COLS;
@@ -143,15 +163,19 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
     double *i3s = gnd + 3 * N;             // [2N]   I3 of the I rows (flux integrals)
     double *red = i3s + 2 * N;             // [16]
 
+    // thread -> state row: t < 3N up-going (+mu), 3N <= t < 6N down-going; kk = c*N + jj in both halves
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool active = t < R6;
-    const int c = active ? t / (2 * N) : 0;
-    const int d = active ? t % (2 * N) : 0;
-    const bool up = d < N;
-    const int jj = up ? d : d - N;         // 0-based index of |direction|
+    const bool up = t < 3 * N;
+    const int kk = active ? (up ? t : t - 3 * N) : 0;
+    const int c = kk / N;
+    const int jj = kk % N;                 // 0-based index of |direction|
+    const int d = up ? jj : N + jj;
+    const int rl = up ? kk : KH + kk;      // LDS row of this thread
+    const int rsv = c * 2 * N + d;         // row in the order-1 vector tables (sv)
     const double mu = cx.mu[jj];
     const int recoff = c * W + N + (up ? (jj + 1) : -(jj + 1));
-    const size_t mper = (size_t)cx.rtp * cx.ks2 * 128;
+    const size_t mper = (size_t)2 * cx.rtph * cx.ks2h * 128;
     const int S1 = cx.smax + 1;
 
     {   // one workgroup = one bin (grid = nb): no bin loop, so per-bin constants are not kept live elsewhere
@@ -205,16 +229,16 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
             const double *arow = att + jj;
             if (up) {
                 double z = bcv;
-                double snext = fld[nt * CS + t];
-                fld[nt * CS + t] = z;
+                double snext = fld[nt * CS + rl];
+                fld[nt * CS + rl] = z;
                 if (jhi == nt) xhi = z;
 #pragma unroll 1
                 for (int i = nt - 1; i >= 0; --i) {
                     const double a_t = arow[i * N], dt = dtau[i];
-                    const double bq = fld[i * CS + t];
+                    const double bq = fld[i * CS + rl];
                     const double a = (snext - bq) * idtau[i];
                     z = z * a_t + (1.0 - a_t) * (a * mu + bq) - a * (a_t * dt);
-                    fld[i * CS + t] = z;
+                    fld[i * CS + rl] = z;
                     snext = bq;
                     if (i == jlo) xlo = z;
                     if (i == jhi) xhi = z;
@@ -222,17 +246,17 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
                 xb = z;
             } else {
                 double z = 0.;
-                double sprev = fld[t];
-                fld[t] = 0.;
+                double sprev = fld[rl];
+                fld[rl] = 0.;
                 if (jlo == 0) xlo = 0.;
                 const double rmuk = -mu;
 #pragma unroll 1
                 for (int i = 1; i <= nt; ++i) {
                     const double a_t = arow[(i - 1) * N], dt = dtau[i - 1];
-                    const double bq = fld[i * CS + t];
+                    const double bq = fld[i * CS + rl];
                     const double a = (bq - sprev) * idtau[i - 1];
                     z = z * a_t + (1.0 - a_t) * (a * rmuk + bq) + a * (a_t * dt);
-                    fld[i * CS + t] = z;
+                    fld[i * CS + rl] = z;
                     sprev = bq;
                     if (i == jlo) xlo = z;
                     if (i == jhi) xhi = z;
@@ -284,14 +308,14 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
             // ---- scattering order 1 ------------------------------------------------------------
             const double *svp = cx.sv + (size_t)s * 4 * KP;
             if (active) {
-                const double sva = svp[t], svr = svp[KP + t];
-                const double sfa = svp[2 * KP + t], sfr = svp[3 * KP + t];
+                const double sva = svp[rsv], svr = svp[KP + rsv];
+                const double sfa = svp[2 * KP + rsv], sfr = svp[3 * KP + rsv];
 #pragma unroll 1
                 for (int i = 0; i <= nt; i++) {
                     double v = ch[i] * (sva * xdel[i] + svr * ydel[i]);              // SOS_OS.F:2557-2559
                     if (cx.ifresnel == 1 && (up ? (i < nt) : (i >= 1)))
                         v = v + fco[i] * (sfa * xdel[i] + sfr * ydel[i]);            // SOS_OS.F:3280-3289
-                    fld[i * CS + t] = v;
+                    fld[i * CS + rl] = v;
                 }
             }
             double bc = 0., dirterm = 0.;
@@ -325,24 +349,30 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
                 if (ig > cx.igmax) break;
                 iglast = ig;
                 // source function: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
-                v4d acc[RTW][CT];
+                v4d acc[2][RTWH][CT];
 #pragma unroll
-                for (int rt = 0; rt < RTW; rt++)
+                for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ct++) acc[rt][ct] = (v4d){0., 0., 0., 0.};
+                    for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
                 __syncthreads();
-                gemm_source<RTW, CT>(acc, cx.mp_aer + (size_t)s * mper, cx.mp_ray + (size_t)(s <= 2 ? s : 0) * mper,
-                                     has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2, fld, CS, xdel, ydel, lane, wv);
+                gemm_source<RTWH, CT>(acc, cx.mp_aer + (size_t)s * mper, cx.mp_ray + (size_t)(s <= 2 ? s : 0) * mper,
+                                      has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2h, cx.rtph, 2 * N, fld, CS, KH, xdel, ydel, lane, wv);
                 __syncthreads();
 #pragma unroll
-                for (int rt = 0; rt < RTW; rt++)
+                for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
                     for (int ct = 0; ct < CT; ct++) {
                         const int col = ct * 16 + (lane & 15);
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const int row = (wv * RTW + rt) * 16 + (lane >> 4) + 4 * e;
-                            if (row < R6 && col <= nt) fld[col * CS + row] = acc[rt][ct][e];
+                            const int row = (wv * RTWH + rt) * 16 + (lane >> 4) + 4 * e;   // half-system index kk
+                            if (row < 3 * N && col <= nt) {
+                                const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                                fld[col * CS + row] = ea + eb;                               // S(+mu)
+                                fld[col * CS + KH + row] = (row < 2 * N) ? (ea - eb) : (eb - ea);   // S(-mu) = g (E^A - E^B)
+                            }
                         }
                     }
                 __syncthreads();
@@ -415,16 +445,17 @@ __global__ __launch_bounds__(256, (RTW * CT <= 8) ? 2 : 1) void k_sos_os(const S
 static size_t lds_bytes_for(int n, int ct)
 {
     const int cols = 16 * ct;
-    const int kp = sos_round_up(6 * n, 8);
-    const size_t dbl = (size_t)cols * (kp + 2) + (size_t)cols * n + 7 * cols + 3 * n + 2 * n + 16;
+    const int kh = sos_round_up(3 * n, 8);
+    const size_t dbl = (size_t)cols * (2 * kh + 2) + (size_t)cols * n + 7 * cols + 3 * n + 2 * n + 16;
     return dbl * sizeof(double);
 }
 
 int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes)
 {
     if (n < 1 || n > 85 || nt_max < 1) return SOSGPU_E_UNSUPPORTED;
-    const int rt = (6 * n + 15) / 16;
-    const int r = (rt + 3) / 4;
+    const int kh = sos_round_up(3 * n, 8);
+    const int rth = (kh + 15) / 16;
+    const int r = (rth + 3) / 4;
     int c;
     if (nt_max + 1 <= 32) c = 2;
     else if (nt_max + 1 <= 64) c = 4;
@@ -437,10 +468,10 @@ int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes)
     return 0;
 }
 
-template <int RTW, int CT>
+template <int RTWH, int CT>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
-    auto kern = k_sos_os<RTW, CT>;
+    auto kern = k_sos_os<RTWH, CT>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -2;
     const int grid = bn.nb;
@@ -454,10 +485,10 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     size_t lds;
     const int rc = sos_os_variant(cx.n, nt_max, &rtw, &ct, &lds);
     if (rc) return rc;
-    if (cx.rtp != 4 * rtw) return SOSGPU_E_UNSUPPORTED;
+    if (cx.rtph != 4 * rtw) return SOSGPU_E_UNSUPPORTED;
 #define V(R, C) if (rtw == R && ct == C) return launch_variant<R, C>(cx, bn, lds, st);
-    V(1, 2) V(2, 2) V(3, 2) V(4, 2) V(5, 2) V(6, 2) V(7, 2) V(8, 2)
-    V(1, 4) V(2, 4) V(3, 4) V(4, 4) V(5, 4) V(6, 4)
+    V(1, 2) V(2, 2) V(3, 2) V(4, 2)
+    V(1, 4) V(2, 4) V(3, 4)
 #undef V
     return SOSGPU_E_UNSUPPORTED;
 }
