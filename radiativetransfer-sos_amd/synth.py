@@ -38,7 +38,8 @@ def gauss_angles(ng, tetas_deg):
         mu = np.insert(mu, pos, mus)
         wt = np.insert(wt, pos, 0.0)
         n0 = pos + 1
-    return _round_sig(mu, 15), _round_sig(wt, 15), n0
+    # D21.14 in SOS_UsedAngles.txt (SOS_ANGLES.F:647) keeps 14 significant digits
+    return _round_sig(mu, 14), _round_sig(wt, 14), n0
 
 
 def hg_phase(os_nb, g, polar=(0.9, 0.85, -0.08)):
@@ -53,35 +54,41 @@ def hg_phase(os_nb, g, polar=(0.9, 0.85, -0.08)):
 
 
 def profile(nt, tau_r=0.0948, tau_a=0.3, k_abs=0.0, hr=8.0, ha=2.0, hg=4.0, ztoa=120.0):
-    """One bin's profile on nt layers of equal total optical thickness (the reference places its levels
-    by bisection on tau(z) too, SOS_PROFIL.F:1210-1329).  Returns h, xdel, ydel, zprof (nt+1 each),
-    i.e. the PROFIL_TMP columns before SOS.F's truncation rescale."""
+    """Profile(s) on nt layers of equal total optical thickness (the reference places its levels by
+    bisection on tau(z) too, SOS_PROFIL.F:1210-1329).  k_abs may be a scalar (one bin) or an array (one bin
+    per element, vectorised).  Returns h, xdel, ydel, zprof ([nt+1] or [nb][nt+1]), i.e. the PROFIL_TMP
+    columns before SOS.F's truncation rescale."""
+    k = np.atleast_1d(np.asarray(k_abs, dtype=np.float64))[:, None]
     def tr(z): return tau_r * np.exp(-z / hr)
     def ta(z): return tau_a * np.exp(-z / ha)
-    def tg(z): return k_abs * np.exp(-z / hg)
+    def tg(z): return k * np.exp(-z / hg)
     def tt(z): return tr(z) + ta(z) + tg(z)
-    t0, t1 = tt(ztoa), tt(0.0)
-    targets = t0 + (t1 - t0) * np.arange(nt + 1) / nt
-    lo = np.zeros(nt + 1)
-    hi = np.full(nt + 1, ztoa)
+    zt = np.full((k.shape[0], 1), ztoa)
+    t0, t1 = tt(zt), tt(np.zeros_like(zt))
+    targets = t0 + (t1 - t0) * (np.arange(nt + 1) / nt)[None, :]
+    lo = np.zeros_like(targets)
+    hi = np.full_like(targets, ztoa)
     for _ in range(80):
         mid = 0.5 * (lo + hi)
         big = tt(mid) > targets
         lo = np.where(big, mid, lo)
         hi = np.where(big, hi, mid)
     z = 0.5 * (lo + hi)
-    z[0], z[-1] = ztoa, 0.0
+    z[:, 0], z[:, -1] = ztoa, 0.0
     z = np.round(z, 5)  # F10.5
     h = tt(z)
-    xdel = np.zeros(nt + 1)
-    ydel = np.zeros(nt + 1)
-    dt = np.diff(h)
-    xdel[1:] = np.diff(ta(z)) / dt
-    ydel[1:] = np.diff(tr(z)) / dt
-    d0 = tau_r / hr * np.exp(-ztoa / hr) + tau_a / ha * np.exp(-ztoa / ha) + k_abs / hg * np.exp(-ztoa / hg)
-    xdel[0] = (tau_a / ha * np.exp(-ztoa / ha)) / d0
-    ydel[0] = (tau_r / hr * np.exp(-ztoa / hr)) / d0
-    return _round_sig(h, 8), _round_sig(xdel, 8), _round_sig(ydel, 8), z
+    xdel = np.zeros_like(h)
+    ydel = np.zeros_like(h)
+    dt = np.diff(h, axis=1)
+    xdel[:, 1:] = np.diff(ta(z), axis=1) / dt
+    ydel[:, 1:] = np.diff(tr(z), axis=1) / dt
+    d0 = tau_r / hr * np.exp(-ztoa / hr) + tau_a / ha * np.exp(-ztoa / ha) + k[:, 0] / hg * np.exp(-ztoa / hg)
+    xdel[:, 0] = (tau_a / ha * np.exp(-ztoa / ha)) / d0
+    ydel[:, 0] = (tau_r / hr * np.exp(-ztoa / hr)) / d0
+    out = (_round_sig(h, 8), _round_sig(xdel, 8), _round_sig(ydel, 8), z)
+    if np.ndim(k_abs) == 0:
+        return tuple(a[0] for a in out)
+    return out
 
 
 def ckd_bins(nb, nt, seed=1234, tau_r=0.0948, tau_a=0.3, kmin=1e-3, kmax=30.0):
@@ -91,9 +98,7 @@ def ckd_bins(nb, nt, seed=1234, tau_r=0.0948, tau_a=0.3, kmin=1e-3, kmax=30.0):
     rng = np.random.default_rng(seed)
     k = np.exp(rng.uniform(np.log(kmin), np.log(kmax), nb))
     aik = rng.dirichlet(np.ones(nb)) if nb > 1 else np.ones(1)
-    H = np.zeros((nb, nt + 1)); X = np.zeros_like(H); Y = np.zeros_like(H); Z = np.zeros_like(H)
-    for b in range(nb):
-        H[b], X[b], Y[b], Z[b] = profile(nt, tau_r, tau_a, k[b])
+    H, X, Y, Z = profile(nt, tau_r, tau_a, k)
     return dict(h=H, xdel=X, ydel=Y, zprof=Z, aik=aik, k_abs=k)
 
 
