@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libsosgpu.so")
+# SOSGPU_LIB selects an alternative build of the same library (A/B experiments); default = in-tree libsosgpu.so
+SO_PATH = os.environ.get("SOSGPU_LIB") or os.path.join(HERE, "libsosgpu.so")
 
 # every symbol include/sosgpu.h declares (checked by tests/test_cabi.py)
 EXPORTS = [

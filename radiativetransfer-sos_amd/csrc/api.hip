@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -29,6 +30,8 @@ struct sosgpu_ctx {
     hipStream_t last_stream;
     int nt_max_hint;
     double ind_surf;
+    double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
+    size_t scratch_doubles;
 };
 
 extern "C" const char *sosgpu_version(void) { return "sosgpu 0.1 (gfx950)"; }
@@ -85,6 +88,8 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->timed = false;
     cx->last_stream = nullptr;
     cx->ind_surf = wv->ind_surf;
+    cx->scratch = nullptr;
+    cx->scratch_doubles = 0;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -162,6 +167,7 @@ extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
     if (!cx) return SOSGPU_OK;
     hipSetDevice(cx->device);
     for (void *p : cx->allocs) hipFree(p);
+    if (cx->scratch) hipFree(cx->scratch);
     if (cx->ev0) hipEventDestroy(cx->ev0);
     if (cx->ev1) hipEventDestroy(cx->ev1);
     delete cx;
@@ -211,15 +217,45 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     if (cx->d.imat_surf && !cx->d.rsurf) return SOSGPU_E_ARG;
     if (nb == 0) return SOSGPU_OK;
     HIPCHK(hipSetDevice(cx->device));
-    SosBins bn;
-    bn.nb = nb; bn.lp = lp; bn.nt = d_nt; bn.iborm = d_iborm; bn.jout = d_jout; bn.prof = d_prof; bn.zz = d_zz;
-    bn.rec = d_rec; bn.flux = d_flux; bn.norders = d_norders; bn.iglast = d_iglast;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipEventRecord(cx->ev0, st));
-    // lp - 1 bounds every NT of the batch (the host pads the level axis to lp)
-    const int rc = launch_sos_os(cx->d, bn, lp - 1, st);
-    if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
+    // variant: field in LDS, or (NT too large) field in a per-bin HBM scratch, launched in sub-batches so that
+    // the scratch stays below ~8 GiB
+    int rtw, ct, big;
+    size_t lds;
+    const int nt_max = lp - 1;          // lp - 1 bounds every NT of the batch (the host pads the level axis to lp)
+    int rc = sos_os_variant(cx->d.n, nt_max, &rtw, &ct, &lds, &big);
     if (rc) return rc;
+    int per_launch = nb;
+    size_t per_bin = 0;
+    const int lpb = sos_round_up(lp, 32);
+    if (big) {
+        per_bin = sos_os_scratch_doubles(cx->d.n, lpb);
+        const size_t cap = ((size_t)8 << 30) / sizeof(double);
+        per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
+        const size_t need = per_bin * per_launch;
+        if (need > cx->scratch_doubles) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (cx->scratch) hipFree(cx->scratch);
+            cx->scratch = nullptr;
+            cx->scratch_doubles = 0;
+            HIPCHK(hipMalloc((void **)&cx->scratch, need * sizeof(double)));
+            cx->scratch_doubles = need;
+        }
+    }
+    HIPCHK(hipEventRecord(cx->ev0, st));
+    const int S1 = cx->d.smax + 1, W = cx->d.w;
+    for (int b0 = 0; b0 < nb; b0 += per_launch) {
+        SosBins bn;
+        bn.nb = std::min(per_launch, nb - b0); bn.lp = lp;
+        bn.nt = d_nt + b0; bn.iborm = d_iborm + b0; bn.jout = d_jout ? d_jout + b0 : nullptr;
+        bn.prof = d_prof + (size_t)b0 * 3 * lp; bn.zz = d_zz ? d_zz + b0 : nullptr;
+        bn.rec = d_rec + (size_t)b0 * S1 * 3 * W; bn.flux = d_flux + (size_t)2 * b0;
+        bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
+        bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
+        rc = launch_sos_os(cx->d, bn, nt_max, st);
+        if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
+        if (rc) return rc;
+    }
     HIPCHK(hipEventRecord(cx->ev1, st));
     cx->timed = true;
     cx->last_stream = st;

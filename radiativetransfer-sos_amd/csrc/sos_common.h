@@ -51,6 +51,11 @@ struct SosBins {
     const double *prof, *zz;
     double *rec, *flux;
     int32_t *norders, *iglast;
+    // field-in-HBM variant (NT too large for LDS): per-bin scratch of scr_stride doubles laid out
+    // [lpb][2*KH] field | [lpb][N] attenuations | [7][lpb] level vectors
+    double *scratch;
+    size_t scr_stride;
+    int lpb;
 };
 
 static inline int sos_round_up(int a, int b) { return (a + b - 1) / b * b; }

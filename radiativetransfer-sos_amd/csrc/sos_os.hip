@@ -24,6 +24,11 @@
 #include "kernels.h"
 
 #define SOSGPU_E_UNSUPPORTED -3
+#ifndef SOS_SCAN_UNROLL
+#define SOS_SCAN_UNROLL 4
+#endif
+#define SOS_PRAGMA(x) _Pragma(#x)
+#define SOS_UNROLL(n) SOS_PRAGMA(unroll n)
 
 __device__ __forceinline__ double wave_max(double v)
 {
@@ -144,24 +149,32 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
     }
 }
 
-template <int RTWH, int CT>
+// BIG = false: the whole field (NT+1 <= 16*CT levels) lives in LDS.
+// BIG = true : the field, the attenuation table and the level vectors live in a per-bin HBM/L2 scratch
+//              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of
+//              16*CT levels staged through LDS, the formal solution streams the scratch with batched loads.
+template <int RTWH, int CT, bool BIG>
 __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
     constexpr int COLS = 16 * CT;
     const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
-    double *fld = smem;                    // [COLS][CS]   field / source, [level][+mu rows | -mu rows]
-    double *att = fld + COLS * CS;         // [COLS][N]    exp(-dtau_i/mu_j), layer i = levels i..i+1
-    double *dtau = att + COLS * N;         // [COLS] each:
-    double *idtau = dtau + COLS;
-    double *xdel = idtau + COLS;
-    double *ydel = xdel + COLS;
-    double *ch = ydel + COLS;
-    double *fco = ch + COLS;
-    double *hh = fco + COLS;
-    double *gnd = hh + COLS;               // [3][N] down-going field at the ground, order ig-1
+    const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
+    const int FS = BIG ? 2 * cx.kh : CS;   // level stride of the field storage
+    double *cbuf = smem;                   // [COLS][CS]  LDS: the field itself, or the staging chunk (BIG)
+    double *gnd = cbuf + COLS * CS;        // [3][N] down-going field at the ground, order ig-1
     double *i3s = gnd + 3 * N;             // [2N]   I3 of the I rows (flux integrals)
     double *red = i3s + 2 * N;             // [16]
+    double *sbase = BIG ? bn.scratch + (size_t)blockIdx.x * bn.scr_stride : red + 16;
+    double *fld = BIG ? sbase : cbuf;      // [LPB][FS]   field / source, [level][+mu rows | -mu rows]
+    double *att = BIG ? sbase + (size_t)LPB * FS : sbase;   // [LPB][N] exp(-dtau_i/mu_j), layer i = levels i..i+1
+    double *dtau = att + (size_t)LPB * N;  // [LPB] each:
+    double *idtau = dtau + LPB;
+    double *xdel = idtau + LPB;
+    double *ydel = xdel + LPB;
+    double *ch = ydel + LPB;
+    double *fco = ch + LPB;
+    double *hh = fco + LPB;
 
     // thread -> state row: t < 3N up-going (+mu), 3N <= t < 6N down-going; kk = c*N + jj in both halves
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         const double zz = uniform_f64(jout ? bn.zz[b] : 0.);
         const int jlo = jout ? jout - 1 : -1, jhi = jout ? jout : -1;
         // shape guard (uniform): a malformed bin is flagged (norders = -1), never indexed out of bounds
-        if (nt < 1 || nt >= COLS || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
+        if (nt < 1 || nt >= LPB || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
             if (t == 0) bn.norders[b] = -1;
             return;
         }
@@ -194,22 +207,24 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         double *recb = bn.rec + (size_t)b * S1 * 3 * W;
 
         __syncthreads();
-        for (int i = t; i < COLS * CS; i += 256) fld[i] = 0.;
-        if (t < COLS) {
-            const bool in = t <= nt;
-            hh[t] = in ? pf[t] : 0.;
-            xdel[t] = in ? pf[bn.lp + t] : 0.;
-            ydel[t] = in ? pf[2 * bn.lp + t] : 0.;
+        for (size_t i = t; i < (size_t)LPB * FS; i += 256) fld[i] = 0.;
+        for (int i = t; i < LPB; i += 256) {
+            const bool in = i <= nt;
+            hh[i] = in ? pf[i] : 0.;
+            xdel[i] = in ? pf[bn.lp + i] : 0.;
+            ydel[i] = in ? pf[2 * bn.lp + i] : 0.;
         }
         __syncthreads();
         const double htot = uniform_f64(hh[nt]);
-        if (t < COLS) {
-            if (t < nt) { const double dt = hh[t + 1] - hh[t]; dtau[t] = dt; idtau[t] = 1.0 / dt; }
-            else { dtau[t] = 0.; idtau[t] = 0.; }
-            ch[t] = (t <= nt) ? exp(-hh[t] / cx.mus) / 4. : 0.;                               // SOS_OS.F:837-839
-            fco[t] = (t <= nt) ? (exp(-2. * htot / cx.mus) / 4.) * exp(hh[t] / cx.mus) : 0.;  // SOS_OS.F:3219,3278
+        int aer_l = 0;
+        for (int i = t; i < LPB; i += 256) {
+            if (i < nt) { const double dt = hh[i + 1] - hh[i]; dtau[i] = dt; idtau[i] = 1.0 / dt; }
+            else { dtau[i] = 0.; idtau[i] = 0.; }
+            ch[i] = (i <= nt) ? exp(-hh[i] / cx.mus) / 4. : 0.;                               // SOS_OS.F:837-839
+            fco[i] = (i <= nt) ? (exp(-2. * htot / cx.mus) / 4.) * exp(hh[i] / cx.mus) : 0.;  // SOS_OS.F:3219,3278
+            if (i <= nt && xdel[i] != 0.) aer_l = 1;
         }
-        const int has_aer = uniform_i32(__syncthreads_or((t <= nt && t < COLS && xdel[t] != 0.) ? 1 : 0));
+        const int has_aer = uniform_i32(__syncthreads_or(aer_l));
         for (int i = t; i < nt * N; i += 256) att[i] = exp(-dtau[i / N] / cx.mu[i % N]);      // SOS_OS.F:2291,2335
         // bin-constant exponentials of the ground boundary terms (SOS_OS.F:979,985,1068-1077)
         const double e_sun = uniform_f64(exp(-htot / cx.mus));
@@ -226,19 +241,22 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         double xb, xlo = 0., xhi = 0.;
         auto scan_row = [&](double bcv) {
             if (!active) { xb = 0.; return; }
+#ifdef SOS_SCAN_PRIO
+            __builtin_amdgcn_s_setprio(SOS_SCAN_PRIO);
+#endif
             const double *arow = att + jj;
             if (up) {
                 double z = bcv;
-                double snext = fld[nt * CS + rl];
-                fld[nt * CS + rl] = z;
+                double snext = fld[(size_t)nt * FS + rl];
+                fld[(size_t)nt * FS + rl] = z;
                 if (jhi == nt) xhi = z;
-#pragma unroll 1
-                for (int i = nt - 1; i >= 0; --i) {
+SOS_UNROLL(SOS_SCAN_UNROLL)
+                for (int i = nt - 1; i >= 0; --i) {   // in BIG mode the unrolled body batches the scratch loads
                     const double a_t = arow[i * N], dt = dtau[i];
-                    const double bq = fld[i * CS + rl];
+                    const double bq = fld[(size_t)i * FS + rl];
                     const double a = (snext - bq) * idtau[i];
                     z = z * a_t + (1.0 - a_t) * (a * mu + bq) - a * (a_t * dt);
-                    fld[i * CS + rl] = z;
+                    fld[(size_t)i * FS + rl] = z;
                     snext = bq;
                     if (i == jlo) xlo = z;
                     if (i == jhi) xhi = z;
@@ -250,13 +268,13 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                 fld[rl] = 0.;
                 if (jlo == 0) xlo = 0.;
                 const double rmuk = -mu;
-#pragma unroll 1
+SOS_UNROLL(SOS_SCAN_UNROLL)
                 for (int i = 1; i <= nt; ++i) {
                     const double a_t = arow[(i - 1) * N], dt = dtau[i - 1];
-                    const double bq = fld[i * CS + rl];
+                    const double bq = fld[(size_t)i * FS + rl];
                     const double a = (bq - sprev) * idtau[i - 1];
                     z = z * a_t + (1.0 - a_t) * (a * rmuk + bq) + a * (a_t * dt);
-                    fld[i * CS + rl] = z;
+                    fld[(size_t)i * FS + rl] = z;
                     sprev = bq;
                     if (i == jlo) xlo = z;
                     if (i == jhi) xhi = z;
@@ -264,6 +282,9 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                 xb = z;
                 gnd[c * N + jj] = z;
             }
+#ifdef SOS_SCAN_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
 
         double i4 = 0., i5 = 0.;
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                     double v = ch[i] * (sva * xdel[i] + svr * ydel[i]);              // SOS_OS.F:2557-2559
                     if (cx.ifresnel == 1 && (up ? (i < nt) : (i >= 1)))
                         v = v + fco[i] * (sfa * xdel[i] + sfr * ydel[i]);            // SOS_OS.F:3280-3289
-                    fld[i * CS + rl] = v;
+                    fld[(size_t)i * FS + rl] = v;
                 }
             }
             double bc = 0., dirterm = 0.;
@@ -349,32 +370,58 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                 if (ig > cx.igmax) break;
                 iglast = ig;
                 // source function: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
-                v4d acc[2][RTWH][CT];
+                const int nchunk = BIG ? (nt + COLS) / COLS : 1;
+#pragma unroll 1
+                for (int chk = 0; chk < nchunk; chk++) {
+                    const int l0 = chk * COLS;                 // first level of this chunk
+                    v4d acc[2][RTWH][CT];
 #pragma unroll
-                for (int sy = 0; sy < 2; sy++)
+                    for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                        for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                            for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
+                    __syncthreads();
+                    if (BIG) {                                 // stage the chunk: scratch -> LDS (16 B per lane, coalesced)
+                        const int per_lev = KH;                // v2d per level (2*KH doubles)
+                        for (int q = t; q < COLS * per_lev; q += 256) {
+                            const int col = q / per_lev, r2 = q % per_lev;
+                            v2d v = {0., 0.};
+                            if (l0 + col <= nt) v = *reinterpret_cast<const v2d *>(fld + (size_t)(l0 + col) * FS + 2 * r2);
+                            *reinterpret_cast<v2d *>(cbuf + (size_t)col * CS + 2 * r2) = v;
+                        }
+                        __syncthreads();
+                    }
+                    gemm_source<RTWH, CT>(acc, cx.mp_aer + (size_t)s * mper, cx.mp_ray + (size_t)(s <= 2 ? s : 0) * mper,
+                                          has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2h, cx.rtph, 2 * N, cbuf, CS, KH,
+                                          xdel + l0, ydel + l0, lane, wv);
+                    __syncthreads();
 #pragma unroll
                     for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
-                        for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
-                __syncthreads();
-                gemm_source<RTWH, CT>(acc, cx.mp_aer + (size_t)s * mper, cx.mp_ray + (size_t)(s <= 2 ? s : 0) * mper,
-                                      has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2h, cx.rtph, 2 * N, fld, CS, KH, xdel, ydel, lane, wv);
-                __syncthreads();
+                        for (int ct = 0; ct < CT; ct++) {
+                            const int col = ct * 16 + (lane & 15);
 #pragma unroll
-                for (int rt = 0; rt < RTWH; rt++)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ct++) {
-                        const int col = ct * 16 + (lane & 15);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int row = (wv * RTWH + rt) * 16 + (lane >> 4) + 4 * e;   // half-system index kk
-                            if (row < 3 * N && col <= nt) {
-                                const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
-                                fld[col * CS + row] = ea + eb;                               // S(+mu)
-                                fld[col * CS + KH + row] = (row < 2 * N) ? (ea - eb) : (eb - ea);   // S(-mu) = g (E^A - E^B)
+                            for (int e = 0; e < 4; e++) {
+                                const int row = (wv * RTWH + rt) * 16 + (lane >> 4) + 4 * e;   // half-system index kk
+                                if (row < 3 * N && l0 + col <= nt) {
+                                    const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                                    cbuf[col * CS + row] = ea + eb;                               // S(+mu)
+                                    cbuf[col * CS + KH + row] = (row < 2 * N) ? (ea - eb) : (eb - ea);   // S(-mu) = g (E^A - E^B)
+                                }
                             }
                         }
+                    __syncthreads();
+                    if (BIG) {                                 // source chunk: LDS -> scratch
+                        const int per_lev = KH;
+                        for (int q = t; q < COLS * per_lev; q += 256) {
+                            const int col = q / per_lev, r2 = q % per_lev;
+                            if (l0 + col <= nt)
+                                *reinterpret_cast<v2d *>(fld + (size_t)(l0 + col) * FS + 2 * r2) =
+                                    *reinterpret_cast<const v2d *>(cbuf + (size_t)col * CS + 2 * r2);
+                        }
                     }
+                }
                 __syncthreads();
                 scan_row(bc);                                                        // SOS_OS.F:1244
                 g1 = xb;
@@ -442,36 +489,45 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
 // ---------------------------------------------------------------------------------------------
 // variant table
 // ---------------------------------------------------------------------------------------------
-static size_t lds_bytes_for(int n, int ct)
+static size_t lds_bytes_for(int n, int ct, bool big)
 {
     const int cols = 16 * ct;
     const int kh = sos_round_up(3 * n, 8);
-    const size_t dbl = (size_t)cols * (2 * kh + 2) + (size_t)cols * n + 7 * cols + 3 * n + 2 * n + 16;
+    size_t dbl = (size_t)cols * (2 * kh + 2) + 3 * n + 2 * n + 16;
+    if (!big) dbl += (size_t)cols * n + 7 * cols;
     return dbl * sizeof(double);
 }
 
-int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes)
+// returns 0 and the variant (rtw = row tiles per wave and system, ct = column tiles, big) or UNSUPPORTED
+int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes, int *big)
 {
-    if (n < 1 || n > 85 || nt_max < 1) return SOSGPU_E_UNSUPPORTED;
+    if (n < 1 || n > 85 || nt_max < 1 || nt_max > 1023) return SOSGPU_E_UNSUPPORTED;
     const int kh = sos_round_up(3 * n, 8);
     const int rth = (kh + 15) / 16;
     const int r = (rth + 3) / 4;
-    int c;
-    if (nt_max + 1 <= 32) c = 2;
-    else if (nt_max + 1 <= 64) c = 4;
-    else return SOSGPU_E_UNSUPPORTED;
-    const size_t lb = lds_bytes_for(n, c);
+    int c = 0, b = 0;
+    if (nt_max + 1 <= 32 && lds_bytes_for(n, 2, false) <= 160 * 1024) c = 2;
+    else if (nt_max + 1 <= 64 && r <= 3 && lds_bytes_for(n, 4, false) <= 160 * 1024) c = 4;
+    else { c = 2; b = 1; }
+    const size_t lb = lds_bytes_for(n, c, b);
     if (lb > 160 * 1024) return SOSGPU_E_UNSUPPORTED;
     if (rtw) *rtw = r;
     if (ct) *ct = c;
     if (lds_bytes) *lds_bytes = lb;
+    if (big) *big = b;
     return 0;
 }
 
-template <int RTWH, int CT>
+size_t sos_os_scratch_doubles(int n, int lpb)
+{
+    const int kh = sos_round_up(3 * n, 8);
+    return (size_t)lpb * (2 * kh) + (size_t)lpb * n + 7 * (size_t)lpb;
+}
+
+template <int RTWH, int CT, bool BIG>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
-    auto kern = k_sos_os<RTWH, CT>;
+    auto kern = k_sos_os<RTWH, CT, BIG>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -2;
     const int grid = bn.nb;
@@ -481,14 +537,16 @@ static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipSt
 
 int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st)
 {
-    int rtw, ct;
+    int rtw, ct, big;
     size_t lds;
-    const int rc = sos_os_variant(cx.n, nt_max, &rtw, &ct, &lds);
+    const int rc = sos_os_variant(cx.n, nt_max, &rtw, &ct, &lds, &big);
     if (rc) return rc;
     if (cx.rtph != 4 * rtw) return SOSGPU_E_UNSUPPORTED;
-#define V(R, C) if (rtw == R && ct == C) return launch_variant<R, C>(cx, bn, lds, st);
-    V(1, 2) V(2, 2) V(3, 2) V(4, 2)
-    V(1, 4) V(2, 4) V(3, 4)
+    if (big && (!bn.scratch || bn.lpb < nt_max + 1)) return SOSGPU_E_UNSUPPORTED;
+#define V(R, C, B) if (rtw == R && ct == C && big == B) return launch_variant<R, C, B>(cx, bn, lds, st);
+    V(1, 2, 0) V(2, 2, 0) V(3, 2, 0) V(4, 2, 0)
+    V(1, 4, 0) V(2, 4, 0) V(3, 4, 0)
+    V(1, 2, 1) V(2, 2, 1) V(3, 2, 1) V(4, 2, 1)
 #undef V
     return SOSGPU_E_UNSUPPORTED;
 }

@@ -52,6 +52,22 @@ def make_case(name):
     elif name == "igmax_n9":              # IGMAX reached
         ng, nt, os_nb, g, kabs = 8, 12, 16, 0.5, [0.0]
         kw = dict(ro=0.3, igmax=4)
+    # ---- NT beyond the LDS-resident variants: field-in-HBM kernel (reference profiles have NT 100..600) ----
+    elif name == "rayleigh_n25_nt101":    # config 1 with the level count SOS_PROFILE really produces
+        ng, nt, os_nb, g, kabs = 24, 101, 80, None, [0.0]
+        kw = dict(ro=0.1)
+    elif name == "aer_n41_nt120":
+        ng, nt, os_nb, g, kabs = 40, 120, 80, 0.75, [0.0, 3.0]
+        kw = dict(ro=0.1)
+    elif name == "fresnel_zout_n25_nt70":
+        ng, nt, os_nb, g, kabs = 24, 70, 48, 0.7, [0.5]
+        kw = dict(ro=0.03, ifresnel=1, ind_surf=1.34, zout=2.0)
+    elif name == "brdf_n13_nt97":
+        ng, nt, os_nb, g, kabs = 12, 97, 24, 0.6, [0.3]
+        kw = dict(ro=0.02, imat_surf=1, zout=0.7)
+    elif name == "aer_n9_nt600":          # CTE_OS_NT = 600 (SOS.h:202)
+        ng, nt, os_nb, g, kabs = 8, 600, 16, 0.5, [1.0]
+        kw = dict(ro=0.1)
     else:
         raise KeyError(name)
     mu, w, n0 = S.gauss_angles(ng, 35.0)
@@ -75,7 +91,8 @@ def make_case(name):
 
 
 ALL_CASES = ["rayleigh_n25", "aer_n41", "aer_n41_g09", "fresnel_n41", "nopolar_n41", "zout_n25_nt60",
-             "brdf_n13", "brdf_zout_n13", "black_n9", "igmax_n9"]
+             "brdf_n13", "brdf_zout_n13", "black_n9", "igmax_n9",
+             "rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600"]
 
 
 def run_cpu(mod, case, b):
