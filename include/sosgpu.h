@@ -151,6 +151,12 @@ int  sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, const int32_t 
  * Synchronises that stream. */
 int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
 
+/* Diagnostic hook: hand the context a device buffer [nb][8] of uint64 that builds compiled with
+ * -DSOS_PROFILE_PHASES fill with per-phase cycle sums of the solver kernel (0 order-1 fill, 1 formal solution,
+ * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.
+ * The shipped build never writes it. */
+int  sosgpu_debug_phase_buffer(sosgpu_ctx *cx, unsigned long long *d_phase);
+
 #ifdef __cplusplus
 }
 #endif

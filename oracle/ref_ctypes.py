@@ -329,3 +329,47 @@ def sos_trphi(rmu, rec, tau, tauout, phi, *, igli=0, n0=1, wind=0.0, ind_surf=1.
         return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+_PROC_I2 = {"imod_aer", "imodele_wmo", "imodele_sf", "mode_param_bilnd", "iprofil", "absprofil", "isurf"}
+_PROC_I4 = {"nbmu_gauss_lum", "nbmu_gauss_mie", "itronc_aer", "igranu", "igmax", "ipolar", "itrphi", "pas_phi",
+            "imode_ckd_calcul", "ier"}
+_PROC_DIR = {"resroot", "dir_mie", "dir_surf"}
+
+
+def sos_proc(kwargs_in_order):
+    """Call the reference SOS_PROC (SOS_PROC.F:415) end to end.  kwargs_in_order: list of (name, value) in the
+    positional order of SOS_PROC (96 inputs incl. ier, trace), e.g. built by the product's
+    run_sos.sos_proc_kwargs.  Strings are blank-padded (350 for directories, 500 for files) and their lengths
+    appended as size_t after all arguments; output scalars are zero on entry.
+    Returns the 23-tuple in the order of run_sos.OUTPUT_NAMES."""
+    os.environ.setdefault("SOS_ABS_ROOT", "/root/reference")
+    args, lens, keep = [], [], []
+    for name, val in kwargs_in_order:
+        if isinstance(val, str):
+            n = 350 if name in _PROC_DIR else LENFIC2
+            b = _fstr(val, n)
+            keep.append(b)
+            args.append(b)
+            lens.append(C.c_size_t(n))
+        elif name == "trace":
+            v = C.c_int32(1 if val else 0); keep.append(v); args.append(C.byref(v))
+        elif name in _PROC_I2:
+            v = C.c_int16(int(val)); keep.append(v); args.append(C.byref(v))
+        elif name in _PROC_I4:
+            v = C.c_int32(int(val)); keep.append(v); args.append(C.byref(v))
+        else:
+            v = C.c_double(float(val)); keep.append(v); args.append(C.byref(v))
+    lum_nbmu = C.c_int32(0)
+    ind_angout = np.zeros(81, dtype=np.int32)
+    phi = np.zeros(361)
+    theta = np.zeros(81)
+    tabs = [np.zeros((361, 81), order="F") for _ in range(14)]
+    scal = [C.c_double(0.0) for _ in range(5)]
+    outs = [C.byref(lum_nbmu), _p(ind_angout), _p(phi), _p(theta)] + [_p(t) for t in tabs] + [C.byref(s) for s in scal]
+
+    def call():
+        lib().sos_proc_(*args, *outs, *lens)
+
+    _big_stack_call(call)
+    return (lum_nbmu.value, ind_angout, phi, theta, *[np.ascontiguousarray(t) for t in tabs], *[s.value for s in scal])

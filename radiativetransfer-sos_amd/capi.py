@@ -16,6 +16,7 @@ EXPORTS = [
     "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
+    "sosgpu_debug_phase_buffer",
 ]
 
 
@@ -77,6 +78,8 @@ def lib():
         L.sosgpu_mat_fresnel_host.argtypes = [i32, vp, vp, dbl, i32, vp]
         L.sosgpu_trphi.restype = i32
         L.sosgpu_trphi.argtypes = [vp, i32, vp, dbl, dbl, i32, vp, i32, dbl, vp, vp]
+        L.sosgpu_debug_phase_buffer.restype = i32
+        L.sosgpu_debug_phase_buffer.argtypes = [vp, vp]
         _lib = L
     return _lib
 

@@ -30,6 +30,7 @@ struct sosgpu_ctx {
     hipStream_t last_stream;
     int nt_max_hint;
     double ind_surf;
+    unsigned long long *phase;   // diagnostic phase-cycle buffer (sosgpu_debug_phase_buffer), else null
     double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
     size_t scratch_doubles;
 };
@@ -90,6 +91,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->ind_surf = wv->ind_surf;
     cx->scratch = nullptr;
     cx->scratch_doubles = 0;
+    cx->phase = nullptr;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -252,6 +254,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         bn.rec = d_rec + (size_t)b0 * S1 * 3 * W; bn.flux = d_flux + (size_t)2 * b0;
         bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
+        bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
         rc = launch_sos_os(cx->d, bn, nt_max, st);
         if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
         if (rc) return rc;
@@ -433,5 +436,13 @@ extern "C" int sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double 
     HIPCHK(hipSetDevice(cx->device));
     launch_trphi(cx->d, nf, d_rec, tau, tauout, nphi, d_phi, igli, sigma2_of_wind(wind), cx->ind_surf, d_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
+// Diagnostic: per-bin phase cycle counters [nb][8] (filled only by builds with -DSOS_PROFILE_PHASES).
+extern "C" int sosgpu_debug_phase_buffer(sosgpu_ctx *cx, unsigned long long *d_phase)
+{
+    if (!cx) return SOSGPU_E_ARG;
+    cx->phase = d_phase;
     return SOSGPU_OK;
 }

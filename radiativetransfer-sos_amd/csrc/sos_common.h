@@ -56,6 +56,7 @@ struct SosBins {
     double *scratch;
     size_t scr_stride;
     int lpb;
+    unsigned long long *phase;   // diagnostic builds only (SOS_PROFILE_PHASES): [nb][8] cycle sums per phase
 };
 
 static inline int sos_round_up(int a, int b) { return (a + b - 1) / b * b; }

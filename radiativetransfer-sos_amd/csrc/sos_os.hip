@@ -27,6 +27,13 @@
 #ifndef SOS_SCAN_UNROLL
 #define SOS_SCAN_UNROLL 4
 #endif
+#ifdef SOS_PROFILE_PHASES
+#define PH_T0() unsigned long long ph_t = __builtin_amdgcn_s_memtime()
+#define PH(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define PH_T0() do {} while (0)
+#define PH(k) do {} while (0)
+#endif
 #define SOS_PRAGMA(x) _Pragma(#x)
 #define SOS_UNROLL(n) SOS_PRAGMA(unroll n)
 
@@ -290,6 +297,10 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
         double i4 = 0., i5 = 0.;
         double sign = -1.;
         int nord = 0;
+#ifdef SOS_PROFILE_PHASES
+        unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 order-1 fill, 1 scan, 2 gemm, 3 writeback, 4 reduce+tests, 5 ground_bc, 6 fourier, 7 init
+#endif
+        PH_T0();
         for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
             sign = -sign;
             const float *rs = cx.imat_surf ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
@@ -351,7 +362,9 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                     dirterm = bc - xr;                                               // SOS_OS.F:1070-1072
                 }
             }
+            PH(0);
             scan_row(bc);
+            PH(1);
             double rii = 0., riilo = 0., riihi = 0.;
             if (cx.imat_surf && active && up) {                                      // SOS_OS.F:1062-1084
                 rii = e_mu * dirterm;
@@ -362,6 +375,7 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
             double i3lo = xlo, dlo = xlo, i3hi = xhi, dhi = xhi;
             __syncthreads();
             bc = ground_bc();
+            PH(5);
 
             // ---- scattering orders >= 2 --------------------------------------------------------
             int ig = 1, iglast = 1;
@@ -396,6 +410,7 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                                           has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2h, cx.rtph, 2 * N, cbuf, CS, KH,
                                           xdel + l0, ydel + l0, lane, wv);
                     __syncthreads();
+                    PH(2);
 #pragma unroll
                     for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
@@ -423,14 +438,19 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                     }
                 }
                 __syncthreads();
+                PH(3);
                 scan_row(bc);                                                        // SOS_OS.F:1244
+                __syncthreads();
+                PH(1);
                 g1 = xb;
                 const double i3n = i3 + g1;
                 double y1 = (ig != 2) ? conv_term(a1, d1, g1, i3) : 0.;              // SOS_PARAM_CONV
                 double y2 = fabs(g1);                                                // SOS_ARRET_DIFFUS_1
                 double y3 = (i3n != 0.0) ? fabs(g1 / i3n) : 0.;                      // SOS_ARRET_DIFFUS_2
                 block_max3(y1, y2, y3, red);
+                PH(4);
                 bc = ground_bc();
+                PH(5);
                 if (ig != 2 && !(y1 > cx.thr_cv)) {                                  // SOS_OS.F:1293-1315
                     i3 = i3 + queue_term(d1, g1);
                     i3lo = i3lo + queue_term(dlo, xlo);
@@ -477,12 +497,16 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                 if (i5 != 0.0) z2 = fabs(i3 / i5);
             }
             block_max3(z1, z2, z3, red);
+            PH(6);
             if (!(fmax(z1, z2) > cx.thr_sf)) break;                                  // SOS_OS.F:1585
         }
         // orders not run: zero records and counts
         for (int i = t + nord * 3 * W; i < S1 * 3 * W; i += 256) recb[i] = 0.;
         for (int i = t + nord; i < S1; i += 256) bn.iglast[(size_t)b * S1 + i] = 0;
         if (t == 0) bn.norders[b] = nord;
+#ifdef SOS_PROFILE_PHASES
+        if (bn.phase && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&bn.phase[(size_t)b * 8 + k], ph_acc[k]);
+#endif
     }
 }
 

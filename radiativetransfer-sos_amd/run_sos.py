@@ -1,0 +1,454 @@
+"""Host-side mirror of the reference's Python front end `binding/run_sos.py`.
+
+Same `-Group.Key` parameter dictionary (run_sos.py:459-559), same user-override merge (:606-609, unknown keys
+dropped), same `set_sos_params` ordering (:319-441), same `sos_proc(**kwargs)` keyword names (:640-695) and
+the same 23-tuple of outputs with the reference shapes (`PHI_FIN(0:360)`, `THETA_FIN(0:80)`, `(361,81)` tables,
+SOS_PROC.F:1168-1204).  Behind that surface the hot path runs on the GPU through the C ABI:
+
+    angles (host)  ->  [aerosol expansion: given]  ->  profile (host)  ->  SOS.F rescale (host)
+      -> sosgpu_glitter (ISURF=1) -> sosgpu_noyaux -> sosgpu_os_solve -> sosgpu_aggregate -> sosgpu_trphi
+
+Scope of this round: everything upstream of the hot path that the reference computes from
+physics tables is NOT rebuilt -- Mie/size distributions (`-AER.*` models) and CKD gas absorption
+(`-AP.AbsProfile.Type` != 7) raise NotImplementedError.  Supported: no-aerosol atmospheres (`-AER.AOTref 0`) or
+a caller-supplied phase-matrix expansion (extension keyword `aer_phase`, not in the reference), exponential
+molecular/aerosol profiles without gas (`-AP.AerProfile.Type 1`, `-AP.AbsProfile.Type 7`), surfaces
+`-SURF.Type` 0 (Lambert), 1 (Lambert + Cox-Munk glitter), 2 (Lambert + flat-sea Fresnel).
+
+Differences from the reference script that are deliberate: errors raise exceptions instead of being
+lost in an `intent(in)` `ier`; `gen_sos_output` imports `ceil` and uses `and` (the reference has `1 & updown == 2`);
+no files are written unless asked (`-SOS.ResBin` path given through `write_result_bin`).
+"""
+import math
+import os
+
+import numpy as np
+
+from .synth import MDF_DEFAULT, _round_sig, rescale_profile
+
+SOS_NOT_DEFINED_VALUE_INT = -999
+SOS_NOT_DEFINED_VALUE_DBLE = -999.0
+SOS_DEFAULT_AER_JUNGE_RMAX = 50.
+SOS_DEFAULT_FICANGRESLUM = "SOS_UsedAngles.txt"
+SOS_DEFAULT_FICANGRESMIE = "Aer_UsedAngles.txt"
+SOS_DEFAULT_FICGRANU = "Aerosols.txt"
+SOS_DEFAULT_RESBIN = "SOS_Result.bin"
+SOS_DEFAULT_RESUP = "SOS_Up.txt"
+SOS_DEFAULT_RESDOWN = "SOS_Down.txt"
+
+# inc/SOS.h constants used by the host-side restatements (REAL*4 literals are widened exactly as Fortran does)
+_F = lambda x: float(np.float32(x))
+CTE_OS_NBMU_MAX = 80
+CTE_OS_NT = 600                      # SOS.h:202
+CTE_OS_NT_MIN = 100                  # SOS.h:229
+CTE_TCOUCHE = _F(0.005)              # SOS.h:208
+CTE_TOA_FIRST_LAYER = _F(0.0002)     # SOS.h:213
+CTE_DELTA_Z = _F(0.05)               # SOS.h:218
+CTE_TOA_ALT = 120.0                  # SOS.h:197
+CTE_HT_STD_PSURF = 1013.0            # SOS.h:192
+CTE_DEFAULT_IGMAX = 100              # SOS.h:383
+CTE_DEFAULT_NBMU_LUM, CTE_DEFAULT_NBMU_MIE = 24, 40          # SOS.h:514,508
+CTE_DEFAULT_OS_NB, CTE_DEFAULT_OS_NS, CTE_DEFAULT_OS_NM = 80, 48, 128   # SOS.h:521-535
+
+# (dictionary key, sos_proc keyword, default) in the positional order of SOS_PROC (SOS_PROC.F:415-470)
+_I, _D = SOS_NOT_DEFINED_VALUE_INT, SOS_NOT_DEFINED_VALUE_DBLE
+PARAMS = [
+    ("-SOS_Main.ResRoot", "resroot", ""), ("-SOS_Main.Log", "ficmain_log", "SOS_Main.Log"),
+    ("-SOS_Main.Wa", "wa_simu", _D), ("-ANG.Rad.NbGauss", "nbmu_gauss_lum", _I),
+    ("-ANG.Rad.UserAngFile", "ficangles_user_lum", "NO_USER_ANGLES"), ("-ANG.Thetas", "tetas", _D),
+    ("-ANG.Rad.ResFile", "ficangles_res_lum", SOS_DEFAULT_FICANGRESLUM), ("-ANG.Aer.NbGauss", "nbmu_gauss_mie", _I),
+    ("-ANG.Aer.UserAngFile", "ficangles_user_mie", "NO_USER_ANGLES"),
+    ("-ANG.Aer.ResFile", "ficangles_res_mie", SOS_DEFAULT_FICANGRESMIE), ("-ANG.Log", "ficanglog", "Angles.Log"),
+    ("-AER.Waref", "waref_aot", _D), ("-AER.AOTref", "aot_ref", _D), ("-AER.Tronca", "itronc_aer", 1),
+    ("-AER.Log", "ficgranu_log", "NO_LOG_FILE"), ("-AER.MieLog", "ficmie_log", "NO_LOG_FILE"),
+    ("-AER.DirMie", "dir_mie", ""), ("-AER.ResFile", "ficgranu", SOS_DEFAULT_FICGRANU), ("-AER.Model", "imod_aer", _I),
+    ("-AER.MMD.MRwa", "rn_wa", _D), ("-AER.MMD.MIwa", "in_wa", _D), ("-AER.MMD.MRwaref", "rn_waref", _D),
+    ("-AER.MMD.MIwaref", "in_waref", _D), ("-AER.MMD.SDtype", "igranu", _I),
+    ("-AER.MMD.LNDradius", "lnd_radius_mmd_aer", _D), ("-AER.MMD.LNDvar", "lnd_lnvar_mmd_aer", _D),
+    ("-AER.MMD.JD.slope", "jd_slope_mmd_aer", _D), ("-AER.MMD.JD.rmin", "jd_rmin_mmd_aer", _D),
+    ("-AER.MMD.JD.rmax", "jd_rmax_mmd_aer", SOS_DEFAULT_AER_JUNGE_RMAX), ("-AER.WMO.Model", "imodele_wmo", _I),
+    ("-AER.WMO.DL", "c_wmo_dl", _D), ("-AER.WMO.WS", "c_wmo_ws", _D), ("-AER.WMO.OC", "c_wmo_oc", _D),
+    ("-AER.WMO.SO", "c_wmo_so", _D), ("-AER.SF.Model", "imodele_sf", _I), ("-AER.SF.RH", "rh", _D),
+    ("-AER.BMD.VCdef", "mode_param_bilnd", _I), ("-AER.BMD.CoarseVC", "user_cv_coarse", _D),
+    ("-AER.BMD.FineVC", "user_cv_fine", _D), ("-AER.BMD.RAOT", "rtauct_waref", _D),
+    ("-AER.BMD.CM.MRwa", "bmd_cm_mrwa", _D), ("-AER.BMD.CM.MIwa", "bmd_cm_miwa", _D),
+    ("-AER.BMD.CM.MRwaref", "bmd_cm_mrwaref", _D), ("-AER.BMD.CM.MIwaref", "bmd_cm_miwaref", _D),
+    ("-AER.BMD.CM.SDradius", "bmd_cm_rmodal", _D), ("-AER.BMD.CM.SDvar", "bmd_cm_var", _D),
+    ("-AER.BMD.FM.MRwa", "bmd_fm_mrwa", _D), ("-AER.BMD.FM.MIwa", "bmd_fm_miwa", _D),
+    ("-AER.BMD.FM.MRwaref", "bmd_fm_mrwaref", _D), ("-AER.BMD.FM.MIwaref", "bmd_fm_miwaref", _D),
+    ("-AER.BMD.FM.SDradius", "bmd_fm_rmodal", _D), ("-AER.BMD.FM.SDvar", "bmd_fm_var", _D),
+    ("-AER.ExtData", "ficextdata_aer", "NO_USER_AEROSOLS_PHAZE_FCT"),
+    ("-AER.DefMixture", "ficmixture_aer", "NO_USER_AEROSOLS_MIXTURE"), ("-AER.UserFile", "ficuser_aer", "NO_USER_AEROSOLS"),
+    ("-AP.Log", "ficprofil_log", "Aerosols.Log"), ("-AP.MOT", "tr", _D), ("-AP.HR", "hr", _D), ("-AP.AerHS.HA", "ha", _D),
+    ("-AP.AerProfile.Type", "iprofil", 1), ("-AP.AerLayer.Zmin", "zmin", _D), ("-AP.AerLayer.Zmax", "zmax", _D),
+    ("-AP.Psurf", "psurf", _D), ("-AP.H2O", "h2o", _D), ("-AP.O3", "o3", _D), ("-AP.CO2", "co2", _D), ("-AP.CH4", "ch4", _D),
+    ("-AP.AbsProfile.Type", "absprofil", _I), ("-AP.AbsProfile.UserFile", "ficabsprofil", "NO_USER_ABS_PROFILE_FILE"),
+    ("-AP.SpectralResol", "nustep", _I), ("-SURF.Type", "isurf", 0), ("-SURF.Dir", "dir_surf", ""),
+    ("-SURF.Log", "ficsurf_log", "NO_LOG_FILE"), ("-SURF.Ind", "surf_ind", _D), ("-SURF.Glitter.Wind", "wind", _D),
+    ("-SURF.Roujean.K0", "k0_roujean", _D), ("-SURF.Roujean.K1", "k1_roujean", _D), ("-SURF.Roujean.K2", "k2_roujean", _D),
+    ("-SURF.Nadal.Alpha", "alpha_nadal", _D), ("-SURF.Nadal.Beta", "beta_nadal", _D),
+    ("-SURF.Maignan.C", "coef_c_maignan", _D), ("-SURF.Alb", "rho", _D), ("-SURF.File", "ficsurf", "DEFAULT"),
+    ("-SOS.Log", "ficsos_log", "SOS.Log"), ("-SOS.ResBin", "ficsos_res_bin", SOS_DEFAULT_RESBIN),
+    ("-SOS.Trans", "fictrans", "NO_OUTPUT"), ("-SOS.Flux", "ficflux", "FicFlux.txt"), ("-SOS.OutputAlt", "zout", -1.0),
+    ("-SOS.IGmax", "igmax", 200), ("-SOS.Ipolar", "ipolar", 1), ("-SOS.View", "itrphi", 2),
+    ("-SOS.View.Phi", "phios", _D), ("-SOS.View.Dphi", "pas_phi", _I), ("-SOS.AbsModeCKD", "imode_ckd_calcul", 1),
+]
+# keys the reference dictionary holds but never forwards to sos_proc (run_sos.py:548-549,557)
+EXTRA_KEYS = {"-SOS.ResFileUp": SOS_DEFAULT_RESUP, "-SOS.ResFileDown": SOS_DEFAULT_RESDOWN, "-SOS.MDF": 0.0279}
+SOS_PROC_KWARGS = [p[1] for p in PARAMS] + ["ier", "trace"]
+OUTPUT_NAMES = ["nblum", "ind_angout", "phi", "vza", "sca_ang_up", "i_up", "q_up", "u_up", "pol_ang_up", "pol_rate_up",
+                "l_pol_up", "sca_ang_down", "i_down", "q_down", "u_down", "pol_ang_down", "pol_rate_down", "l_pol_down",
+                "flux_dir_down", "flux_diff_down", "flux_tot_down", "flux_diff_up", "coef_tronca"]
+
+
+class SosProcError(RuntimeError):
+    """Raised where the reference prints a message and returns IER=1 (SOS_PROC.F:3895-4896)."""
+
+    def __init__(self, msg, ier=1):
+        super().__init__(msg)
+        self.ier = ier
+
+
+def default_parameters():
+    """The reference's `dict_sos_all_parameters` (run_sos.py:459-559)."""
+    d = {k: v for k, _, v in PARAMS}
+    d.update(EXTRA_KEYS)
+    return d
+
+
+def update_parameters(defaults, user):
+    """run_sos.py:606-609: user values override defaults; keys the default dictionary does not hold are dropped."""
+    out = dict(defaults)
+    for k, v in user.items():
+        if k in defaults:
+            out[k] = v
+    return out
+
+
+def set_sos_params(dict_sos, trace=True):
+    """run_sos.py:319-441: the positional tuple handed to sos_proc (96 values: 94 parameters, ier, trace)."""
+    return tuple(dict_sos[k] for k, _, _ in PARAMS) + (0, trace)
+
+
+def sos_proc_kwargs(dict_sos, trace=True):
+    return dict(zip(SOS_PROC_KWARGS, set_sos_params(dict_sos, trace)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host-side restatements of the steps before the hot path (inputs of SOS_OS)
+# ---------------------------------------------------------------------------------------------------------
+def angles(nbmu_gauss, tetas, user_file="NO_USER_ANGLES"):
+    """SOS_ANGLES for the radiance angles (SOS_ANGLES.F:380-466, 713-866): Gauss nodes/weights of the
+    2*NbGauss-point rule on [-1,1] (positive half), optional user angles (weight 0), solar angle inserted
+    with weight 0 unless it coincides with a node, mu descending; values as re-read from SOS_UsedAngles.txt
+    (D21.14).  Returns mu[N], ga[N], n0 (1-based), ind_angout[N] (1 = user angle)."""
+    x, w = np.polynomial.legendre.leggauss(2 * nbmu_gauss)
+    mu = list(x[nbmu_gauss:])
+    wt = list(w[nbmu_gauss:])
+    if user_file != "NO_USER_ANGLES":
+        with open(user_file) as f:
+            for line in f:
+                line = line.strip()
+                if not line:
+                    continue
+                val = float(line.split()[0])
+                if val < 0. or val > 90.:
+                    raise SosProcError("user angle out of [0,90] in %s" % user_file)
+                mu.append(math.cos(val * math.pi / 180.))
+                wt.append(0.0)
+    order = np.argsort(-np.asarray(mu), kind="stable")
+    mu = np.asarray(mu)[order]
+    wt = np.asarray(wt)[order]
+    ind = (wt == 0.0).astype(np.int32)
+    xmus = math.cos(tetas * math.pi / 180.)
+    imus = -1
+    for j in range(len(mu)):
+        if abs(xmus - mu[j]) < _F(0.00001):       # CTE_SEUIL_ECART_MUS, SOS.h:561
+            imus = j + 1
+    if imus == -1:
+        pos = int(np.sum(mu > xmus))
+        mu = np.insert(mu, pos, xmus)
+        wt = np.insert(wt, pos, 0.0)
+        ind = np.insert(ind, pos, 0)
+        imus = pos + 1
+    if len(mu) > CTE_OS_NBMU_MAX:
+        raise SosProcError("number of radiance angles > CTE_OS_NBMU_MAX")
+    return _round_sig(mu, 14), _round_sig(wt, 14), imus, ind
+
+
+def rayleigh_optical_thickness(wa_simu, psurf):
+    """SOS_PROC.F:3333-3334 (CNES formulation); 84.35, 1.225, 1.4 are REAL*4 literals."""
+    return (psurf / CTE_HT_STD_PSURF) * 1.e-4 * (_F(84.35) / wa_simu ** 4 - _F(1.225) / wa_simu ** 5 + _F(1.4) / wa_simu ** 6)
+
+
+def _disc(dt, ta, ha, tr, hr, tim1, zmax_init):
+    """SOS_DISC without gas (SOS_PROFIL.F:1260-1325): altitude where tau(z) = tim1 + dt, by bisection."""
+    ti = tim1 + dt
+    zmax, zmin = zmax_init, 0.0
+    while True:
+        zmoy = (zmax + zmin) / 2.
+        tz = ta * math.exp(-zmoy / ha) + tr * math.exp(-zmoy / hr)
+        xd = abs(ti - tz)
+        if xd < _F(.000001) or zmoy == 0.0:
+            return zmoy
+        if (ti - tz) < 0.0:
+            zmin = zmoy
+        else:
+            zmax = zmoy
+
+
+def profile_nogas(tr, hr, ta, ha):
+    """SOS_PROFILE for IPROFIL=1 without gas absorption (SOS_PROFIL.F:349-508), then the PROFIL_TMP text
+    round trip (format 20 `2X,I5,F10.5,3(E15.8)`, SOS_PROFIL.F:1084,1150).  Returns h, xdel, ydel, zprof."""
+    ttot = tr + ta
+    if (ttot / CTE_OS_NT_MIN) <= CTE_TOA_FIRST_LAYER:
+        nt = CTE_OS_NT_MIN
+        t_layer = ttot / nt
+        t_first = t_layer
+    elif (ttot / CTE_OS_NT_MIN) < CTE_TCOUCHE:
+        nt = CTE_OS_NT_MIN + 1
+        t_first = CTE_TOA_FIRST_LAYER
+        t_layer = (ttot - t_first) / CTE_OS_NT_MIN
+    else:
+        t_first = CTE_TOA_FIRST_LAYER
+        nt = int((ttot - t_first) / CTE_TCOUCHE)
+        t_layer = (ttot - t_first) / nt
+        nt = nt + 1
+    if nt > CTE_OS_NT:
+        raise SosProcError("profile needs more than CTE_OS_NT levels")
+    hmol = np.zeros(nt + 1); haer = np.zeros(nt + 1); z = np.zeros(nt + 1)
+    pcmol = np.zeros(nt + 1); pcaer = np.zeros(nt + 1)
+    if ta == 0.0:                                   # SOS_PROFIL.F:412-429
+        hmol[1] = t_first
+        for i in range(2, nt + 1):
+            hmol[i] = (i - 1) * t_layer + t_first
+        pcmol[:] = 1.0
+        z[0] = CTE_TOA_ALT
+        for i in range(1, nt + 1):
+            z[i] = hr * math.log(tr / hmol[i])
+    else:                                           # SOS_PROFIL.F:437-489
+        z[0] = CTE_TOA_ALT
+        dtau, zz = 0., CTE_TOA_ALT
+        while dtau < t_first:
+            zz = zz - CTE_DELTA_Z
+            dtau = tr * math.exp(-zz / hr) + ta * math.exp(-zz / ha)
+        z[1] = zz
+        vr, va = tr * math.exp(-zz / hr), ta * math.exp(-zz / ha)
+        hmol[1], haer[1] = vr, va
+        pcmol[1], pcaer[1] = vr / dtau, va / dtau
+        pcmol[0], pcaer[0] = pcmol[1], pcaer[1]
+        hprev = dtau
+        for i in range(2, nt):
+            zz = _disc(t_layer, ta, ha, tr, hr, hprev, z[1])
+            z[i] = zz
+            vr, va = tr * math.exp(-zz / hr), ta * math.exp(-zz / ha)
+            hmol[i], haer[i] = vr, va
+            hprev = vr + va
+            vr, va = vr - hmol[i - 1], va - haer[i - 1]
+            pcmol[i], pcaer[i] = vr / (vr + va), va / (vr + va)
+        z[nt] = 0.0
+        hmol[nt], haer[nt] = tr, ta
+        vr, va = tr - hmol[nt - 1], ta - haer[nt - 1]
+        pcmol[nt], pcaer[nt] = vr / (vr + va), va / (vr + va)
+    h = hmol + haer
+    return _round_sig(h, 8), _round_sig(pcaer, 8), _round_sig(pcmol, 8), np.round(z, 5)
+
+
+def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind):
+    """SOS_TRPHI_OPTION (SOS_TRPHI.F:431-615): run the azimuth recomposition on the GPU for the azimuth list of
+    the view mode and pack the fourteen (361,81) tables plus PHI_FIN(361), THETA_FIN(81)."""
+    n = ctx.n
+    teta = np.degrees(np.arccos(ctx.mu))
+    phi_fin = np.zeros(361)
+    theta_fin = np.zeros(81)
+    tabs = {k: np.zeros((361, 81)) for k in ("sca", "i", "q", "u", "ang", "rate", "lpol")}
+    tabs_dn = {k: np.zeros((361, 81)) for k in tabs}
+    if itrphi == 1:
+        phis = [math.pi + phios * math.pi / 180.0, phios * math.pi / 180.0]
+        rows = [0, 1]
+        phi_fin[0] = phios            # set to PHIOS+180 then overwritten by PHIOS (SOS_TRPHI.F:445,504)
+    elif itrphi == 2:
+        iphis = list(range(0, 361, int(pas_phi)))
+        phis = [math.pi * ip / 180.0 for ip in iphis]
+        rows = list(range(len(iphis)))
+        phi_fin[:len(iphis)] = iphis
+    else:
+        raise SosProcError("-SOS.View must be 1 or 2")
+    out = ctx.trphi(rec, nf, tau, tauout, phis, igli=igli, wind=wind).cpu().numpy()
+    theta_fin[:n] = teta
+    names = ["i", "q", "u", "sca", "ang", "rate", "lpol"]       # order of sosgpu_trphi's 7 output rows
+    for k, row in enumerate(rows):
+        for qi, nm in enumerate(names):
+            tabs[nm][row, :n] = out[k, qi, n + 1:]               # up-going jj = 1..N
+            tabs_dn[nm][row, :n] = out[k, qi, :n][::-1]          # down-going jj = -1..-N
+    return phi_fin, theta_fin, tabs, tabs_dn
+
+
+def sos_proc(aer_phase=None, device=0, **kw):
+    """Drop-in for `sos.sos_proc(**kwargs)` (f2py of SOS_PROC, SOS_PROC.F:415) on the MI355X hot path.
+    Returns the reference's 23-tuple (names in OUTPUT_NAMES).
+
+    aer_phase (extension, not a reference keyword): dict(alpha, beta, gamma, zeta [OS_NB+1 each], piz, piztr,
+    a_tronc) -- the content of the reference's Aerosols.txt when `-AER.AOTref` > 0 (the Mie/size-distribution
+    step that produces it is outside this round's scope)."""
+    missing = [k for k in SOS_PROC_KWARGS if k not in kw]
+    if missing:
+        raise TypeError("sos_proc() missing keyword arguments: %s" % ", ".join(missing))
+    p = dict(kw)
+    from .solver import SosContext
+    from . import surface as _surface
+    from . import dist as _dist
+    import torch
+
+    # --- parameter checks the hot path depends on (SOS_PROC.F:1310-2700 has many more; same messages' intent)
+    if p["wa_simu"] == _D:
+        raise SosProcError("-SOS_Main.Wa must be defined")
+    if p["tetas"] == _D or not (0.0 <= p["tetas"] < 90.0):
+        raise SosProcError("-ANG.Thetas must be defined in [0,90[")
+    if p["iprofil"] != 1:
+        raise NotImplementedError("-AP.AerProfile.Type 2 (layer between Zmin/Zmax) is not in this round's scope")
+    if p["absprofil"] != 7:
+        raise NotImplementedError("gas absorption (CKD tables, -AP.AbsProfile.Type != 7) is SURVEY 8f row f1 (next)")
+    if p["isurf"] not in (0, 1, 2):
+        raise NotImplementedError("land BRDF/BPDF surfaces (-SURF.Type >= 3) are SURVEY 8f row f4 (next)")
+    if p["rho"] == _D:
+        raise SosProcError("-SURF.Alb must be defined")
+    if p["aot_ref"] == _D:
+        raise SosProcError("-AER.AOTref must be defined")
+    if p["aot_ref"] != 0.0 and aer_phase is None:
+        raise NotImplementedError("aerosol models (-AER.*: Mie, WMO, S&F, bimodal) are SURVEY 8f row f2 (next); "
+                                  "pass the phase-matrix expansion through aer_phase=")
+    if p["hr"] == _D:
+        raise SosProcError("-AP.HR must be defined")
+    itrphi = p["itrphi"]
+    if itrphi == 1 and p["phios"] == _D:
+        raise SosProcError("-SOS.View.Phi must be defined for -SOS.View 1")
+    if itrphi == 2 and p["pas_phi"] == _I:
+        raise SosProcError("-SOS.View.Dphi must be defined for -SOS.View 2")
+    igmax = CTE_DEFAULT_IGMAX if p["igmax"] == _I else int(p["igmax"])
+
+    # --- SOS_ANGLES (SOS_PROC.F:2738)
+    nb_lum = CTE_DEFAULT_NBMU_LUM if p["nbmu_gauss_lum"] == _I else int(p["nbmu_gauss_lum"])
+    nb_mie = CTE_DEFAULT_NBMU_MIE if p["nbmu_gauss_mie"] == _I else int(p["nbmu_gauss_mie"])
+    os_nb = CTE_DEFAULT_OS_NB if p["nbmu_gauss_mie"] == _I else 2 * nb_mie          # SOS_ANGLES.F:303-312
+    if p["nbmu_gauss_lum"] == _I:
+        os_ns, os_nm = CTE_DEFAULT_OS_NS, CTE_DEFAULT_OS_NM
+    else:
+        os_ns = 2 * nb_lum
+        os_nm = os_nb + os_ns                                                        # SOS_ANGLES.F:325-329
+    mu, ga, n0, ind_ang = angles(nb_lum, p["tetas"], p["ficangles_user_lum"])
+    n = len(mu)
+
+    # --- aerosols: none, or given expansion (stands for SOS_AEROSOLS -> Aerosols.txt -> SOS_PREPA_OS.F:666-700)
+    if p["aot_ref"] == 0.0 or aer_phase is None:
+        ta = 0.0
+        alpha = beta = gamma = zeta = np.zeros(os_nb + 1)
+        piz, piztr, a_tronc = 0.0, 0.0, 0.0
+    else:
+        ta = float(p["aot_ref"])
+        alpha, beta, gamma, zeta = (np.asarray(aer_phase[k], dtype=np.float64) for k in ("alpha", "beta", "gamma", "zeta"))
+        if len(beta) != os_nb + 1:
+            raise SosProcError("aer_phase arrays must have OS_NB+1 = %d entries" % (os_nb + 1))
+        piz, piztr, a_tronc = float(aer_phase["piz"]), float(aer_phase["piztr"]), float(aer_phase.get("a_tronc", 0.0))
+        if p["ha"] == _D:
+            raise SosProcError("-AP.AerHS.HA must be defined")
+
+    # --- molecular optical thickness and profile (SOS_PROC.F:3331-3351, 3518)
+    tr = p["tr"]
+    if tr == _D:
+        if p["psurf"] == _D:
+            raise SosProcError("-AP.MOT or -AP.Psurf must be defined")
+        tr = rayleigh_optical_thickness(p["wa_simu"], p["psurf"])
+    h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, p["ha"] if ta else 1.0)
+    ttot_vrai = h[-1]
+    h, xdel, ydel, iborm = rescale_profile(h, xdel, ydel, a_tronc, piz, piztr, os_nb)   # SOS.F:523-550
+    ttot_tronc = h[-1]
+
+    # --- surface (SOS_PREPA_OS.F:479-497)
+    isurf = int(p["isurf"])
+    igli, ifresnel, imat = int(isurf == 1), int(isurf == 2), int(isurf == 1)
+    rsurf = None
+    if isurf in (1, 2) and p["surf_ind"] == _D:
+        raise SosProcError("-SURF.Ind must be defined for sea surfaces")
+    if isurf == 1:
+        if p["wind"] == _D:
+            raise SosProcError("-SURF.Glitter.Wind must be defined")
+        rsurf = _surface.glitter_matrices(mu, ga, p["wind"], p["surf_ind"], os_nb, os_ns, os_nm, device=device)["rsurf"]
+        if iborm < os_nb:
+            rsurf = rsurf[:iborm + 1].contiguous()
+
+    ctx = SosContext(mu, ga, n0, alpha, beta, gamma, zeta, iborm_max=iborm, ro=p["rho"], imat_surf=imat,
+                     ifresnel=ifresnel, ind_surf=p["surf_ind"] if isurf else 1.34, ron=MDF_DEFAULT,
+                     ipolar=int(p["ipolar"]), igmax=igmax, rsurf=rsurf, device=device)
+    try:
+        # --- the CKD bin loop: without gas absorption there is exactly one bin of weight 1 (SOS_PROC.F:3459-3594)
+        bins = ctx.upload_bins(h[None], xdel[None], ydel[None], iborm=np.array([iborm], dtype=np.int32),
+                               zout=float(p["zout"]), zprof=zprof[None])
+        out = ctx.solve(bins)
+        if p["zout"] == -1.0:
+            tauout = h[0]                                                        # SOS.F:567-568
+        else:
+            j = int(bins["jout"][0])
+            zzv = float(bins["zz"][0])
+            tauout = (1 - zzv) * h[j - 1] + zzv * h[j]                           # SOS.F:572-581
+        scal = np.array([[0.0, ttot_tronc, ttot_vrai, tauout]])
+        rec, sc = ctx.aggregate(out, np.ones(1), scal=scal)
+        torch.cuda.synchronize()
+        if int(out["norders"][0]) < 0:
+            raise SosProcError("SOS_OS: malformed bin")
+        fin = _dist.finish_scalars(sc)
+        nf = int(fin["n_orders"][0])
+        tau_agg, tauout_agg = float(fin["ttot_tronc"][0]), float(fin["tauout"][0])
+        ttot_vrai_agg = float(fin["ttot_vrai"][0])
+        phi_fin, theta_fin, up, dn = trphi_tables(ctx, rec[0], nf, tau_agg, tauout_agg, itrphi, p["phios"], p["pas_phi"],
+                                                  igli, p["wind"] if igli else 0.0)
+        emoins, eplus = float(fin["emoins"][0]), float(fin["eplus"][0])
+    finally:
+        ctx.close()
+    cs = math.cos(math.pi * p["tetas"] / 180.0)
+    tdir_tronc = math.exp(-tau_agg / cs)                                          # SOS_PROC.F:3831-3837
+    tdir_vrai = math.exp(-ttot_vrai_agg / cs)
+    flux_diff_down = emoins + tdir_tronc - tdir_vrai
+    flux_down = emoins + tdir_tronc
+    ind_angout = np.zeros(81, dtype=np.int32)
+    ind_angout[:n] = ind_ang
+    return (n, ind_angout, phi_fin, theta_fin,
+            up["sca"], up["i"], up["q"], up["u"], up["ang"], up["rate"], up["lpol"],
+            dn["sca"], dn["i"], dn["q"], dn["u"], dn["ang"], dn["rate"], dn["lpol"],
+            tdir_vrai, flux_diff_down, flux_down, eplus, a_tronc)
+
+
+def write_result_bin(path, rec):
+    """Write aggregated Fourier records [F][3][W] (I,Q,U) as the reference's SOS_Result.bin: Fortran sequential
+    unformatted, one record per order holding Q(-N:N), U(-N:N), I(-N:N) (SOS_OS.F:1572-1574)."""
+    rec = np.asarray(rec, dtype="<f8")
+    with open(path, "wb") as f:
+        for s in range(rec.shape[0]):
+            payload = np.concatenate([rec[s, 1], rec[s, 2], rec[s, 0]]).tobytes()
+            m = np.array([len(payload)], "<i4").tobytes()
+            f.write(m + payload + m)
+
+
+def gen_sos_output(rep_out, sos_view, updown, zalt, nblum, pas_phi, phi, vza, sca_ang, i_out, q_out, u_out,
+                   pol_ang_out, pol_rate_out, l_pol_out):
+    """run_sos.py:280-317 (SOS_Up.txt / SOS_Down.txt data block; header abridged to the column titles)."""
+    name = "SOS_Up.txt" if updown == 1 else "SOS_Down.txt"
+    with open(os.path.join(rep_out, name), "w") as fic:
+        az = "PHI      " if sos_view == 2 else ""
+        fic.write("#   %sVZA     SCA_ANG        I              Q              U       POL_ANG  POL_RATE    IPOL\n" % az)
+        if sos_view == 1:
+            for it in range(nblum - 1, -1, -1):
+                fic.write("  %7.2f %7.2f  %13.6e  %13.6e  %13.6e  %7.2f %7.2f %13.6e\n" % (
+                    -vza[it], sca_ang[0, it], i_out[0, it], q_out[0, it], u_out[0, it], pol_ang_out[0, it],
+                    pol_rate_out[0, it], l_pol_out[0, it]))
+            for it in range(nblum):
+                fic.write("  %7.2f %7.2f  %13.6e  %13.6e  %13.6e  %7.2f %7.2f %13.6e\n" % (
+                    vza[it], sca_ang[1, it], i_out[1, it], q_out[1, it], u_out[1, it], pol_ang_out[1, it],
+                    pol_rate_out[1, it], l_pol_out[1, it]))
+        else:
+            nbphi = math.ceil(360. / pas_phi)
+            for ip in range(nbphi):
+                for it in range(nblum):
+                    fic.write(" %7.2f %7.2f %7.2f  %13.6e  %13.6e  %13.6e  %7.2f %7.2f %13.6e\n" % (
+                        phi[ip], vza[it], sca_ang[ip, it], i_out[ip, it], q_out[ip, it], u_out[ip, it],
+                        pol_ang_out[ip, it], pol_rate_out[ip, it], l_pol_out[ip, it]))

@@ -1,0 +1,100 @@
+"""The drop-in boundary: radiativetransfer-sos_amd/run_sos.py mirrors binding/run_sos.py.
+CPU: parameter surface (defaults, merge, positional order, keyword names) and the host-side restatements of the
+steps upstream of the hot path (angles, Rayleigh optical thickness, no-gas profile).
+GPU: sos_proc(**kwargs) end to end against the reference SOS_PROC outputs (tests/golden/sos_proc_*.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PROC_CASES = ["cfg1_lambert", "glitter_polar", "flatsea_zout", "nopolar_polar"]
+
+
+def test_parameter_surface(pkg):
+    rs = pkg.run_sos
+    d = rs.default_parameters()
+    # every key of the reference dictionary (binding/run_sos.py:459-559), incl. the three never forwarded
+    assert len(d) == 97 and d["-SOS.IGmax"] == 200 and d["-SOS.View"] == 2 and d["-AER.Tronca"] == 1
+    assert d["-SOS_Main.Wa"] == -999.0 and d["-ANG.Rad.NbGauss"] == -999 and d["-AER.MMD.JD.rmax"] == 50.0
+    assert d["-SURF.File"] == "DEFAULT" and d["-SOS.MDF"] == 0.0279
+    u = rs.update_parameters(d, {"-SOS_Main.Wa": 0.44, " -SURF.Alb": 0.02, "-NOT.A.KEY": 1})
+    assert u["-SOS_Main.Wa"] == 0.44 and " -SURF.Alb" not in u and "-NOT.A.KEY" not in u   # unknown keys dropped
+    t = rs.set_sos_params(u, trace=True)
+    assert len(t) == 96 and t[-1] is True and t[-2] == 0 and t[2] == 0.44
+    kw = rs.sos_proc_kwargs(u)
+    assert list(kw)[:6] == ["resroot", "ficmain_log", "wa_simu", "nbmu_gauss_lum", "ficangles_user_lum", "tetas"]
+    assert list(kw)[-8:] == ["igmax", "ipolar", "itrphi", "phios", "pas_phi", "imode_ckd_calcul", "ier", "trace"]
+    assert len(rs.OUTPUT_NAMES) == 23
+
+
+def test_host_restatements_against_reference_outputs(pkg):
+    """angles / Rayleigh tau / profile restatements reproduce what the reference SOS_PROC reported for cfg 1:
+    25 directions, theta table, Rayleigh optical thickness 9.480316896194211E-02 (reference stdout)."""
+    rs = pkg.run_sos
+    g = np.load(os.path.join(GOLD, "sos_proc_cfg1_lambert.npz"))
+    mu, ga, n0, ind = rs.angles(24, 35.0)
+    assert len(mu) == int(g["nblum"]) == 25 and abs(mu[n0 - 1] - np.cos(np.radians(35.0))) < 1e-14
+    assert np.allclose(np.degrees(np.arccos(mu)), g["vza"][:25], rtol=0, atol=1e-11)
+    assert abs(np.sum(ga) - 1.0) < 1e-13 and ga[n0 - 1] == 0.0
+    tr = rs.rayleigh_optical_thickness(0.550, 1013.0)
+    assert abs(tr - 9.480316896194211e-02) < 1e-16
+    h, xdel, ydel, z = rs.profile_nogas(tr, 8.0, 0.0, 2.0)
+    assert len(h) == 102 and h[0] == 0.0 and abs(h[-1] - tr) < 1e-8 * tr and np.all(xdel == 0) and np.all(ydel == 1)
+    assert z[0] == 120.0 and np.all(np.diff(z) < 0)
+    # with aerosols: levels by bisection, fractions sum to 1, monotone optical depth
+    h, xdel, ydel, z = rs.profile_nogas(0.0948, 8.0, 0.3, 2.0)
+    assert abs(h[-1] - 0.3948) < 1e-8 and np.all(np.diff(h) > 0) and np.allclose(xdel[1:] + ydel[1:], 1.0, atol=1e-7)
+
+
+def test_sos_proc_rejects_out_of_scope(pkg):
+    rs = pkg.run_sos
+    kw = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), {
+        "-SOS_Main.Wa": 0.55, "-ANG.Thetas": 30.0, "-AP.AbsProfile.Type": 2, "-AER.AOTref": 0.0, "-SURF.Alb": 0.1,
+        "-AP.HR": 8.0, "-SOS.View": 1, "-SOS.View.Phi": 0.0}))
+    with pytest.raises(NotImplementedError):
+        rs.sos_proc(**kw)
+    kw["absprofil"] = 7
+    kw["aot_ref"] = 0.3
+    with pytest.raises(NotImplementedError):
+        rs.sos_proc(**kw)
+    with pytest.raises(TypeError):
+        rs.sos_proc(wa_simu=0.55)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PROC_CASES)
+def test_sos_proc_vs_reference(gpu_pkg, name):
+    """run_sos.sos_proc(**kwargs) == reference sos.sos_proc outputs: I,Q,U tables to 1e-9 relative (plus 1e-12 of
+    the I scale for near-zero Q/U), angles/flux scalars to 1e-9; identical table shapes and fill pattern."""
+    rs = gpu_pkg.run_sos
+    g = np.load(os.path.join(GOLD, "sos_proc_%s.npz" % name))
+    user = json.loads(str(g["user_json"]))
+    user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+    kw = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
+    out = rs.sos_proc(**kw)
+    assert len(out) == 23
+    n = int(g["nblum"])
+    assert out[0] == n and np.array_equal(out[1], g["ind_angout"])
+    assert out[2].shape == (361,) and out[3].shape == (81,) and out[5].shape == (361, 81)
+    assert np.allclose(out[2], g["phi"], atol=1e-12) and np.allclose(out[3], g["vza"], atol=1e-10)
+    scale = np.abs(g["i_up"]).max()
+    for k, nm in enumerate(rs.OUTPUT_NAMES):
+        if k < 4:
+            continue
+        exp = g[nm]
+        got = np.asarray(out[k])
+        if nm.startswith(("i_", "q_", "u_", "l_pol")):
+            tol = 1e-9 * np.abs(exp) + 1e-12 * scale
+            assert np.all(np.abs(got - exp) <= tol), (nm, np.abs(got - exp).max())
+        elif nm.startswith("sca_ang"):
+            assert np.allclose(got, exp, rtol=0, atol=1e-9), nm
+        elif nm.startswith(("pol_ang", "pol_rate")):
+            # angle/rate of polarisation are ill-conditioned where Q,U ~ 0: compare where the polarised radiance is significant
+            lp = g["l_pol_up"] if nm.endswith("up") else g["l_pol_down"]
+            m = lp > 1e-6 * scale
+            assert np.allclose(got[m], exp[m], rtol=1e-6, atol=1e-6), nm
+            assert np.array_equal(got == -999.0, exp == -999.0) or not ((got == -999.0) ^ (exp == -999.0))[m].any()
+        else:
+            assert abs(got - exp) <= 1e-9 * abs(exp) + 1e-15, (nm, got, exp)
