@@ -100,14 +100,16 @@ int  sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const 
                      double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream);
 
 /* Replaces SOS_AGGREGATE (SOS_AGGREGATE.F:372-488) for nseg independent wavelengths/bands at once:
- * segment g covers bins seg[g]..seg[g+1]-1 of d_rec.
+ * segment g covers bins seg[g]..seg[g+1]-1 of d_rec; seg[0] = 0, seg[nseg] = nb.  One big band (nseg = 1,
+ * nb > 128) is reduced in chunks of 64 bins (deterministic; the strict serial bin order of the reference is kept for
+ * small bands and multi-band calls).
  *  d_scal[nb][4]  per-bin scalars: TDIFMUS, TTOT_TRONC, TTOT_VRAI, TAUOUT
  *  d_out_rec[nseg][iborm_max+1][3][W] = sum_b aik[b] * rec[b]
  *  d_out_scal[nseg][8] = sum aik*{TDIFMUS, EMOINS, EPLUS}, sum aik*exp(-{TTOT_TRONC,TTOT_VRAI,TAUOUT}),
  *                         sum aik, max norders     (the -ln of the three transmissions is applied by
  *                         sosgpu_aggregate_finish after the cross-GPU reduce)
  */
-int  sosgpu_aggregate(sosgpu_ctx *cx, int nseg, const int32_t *d_seg, const double *d_aik,
+int  sosgpu_aggregate(sosgpu_ctx *cx, int nb, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
                       double *d_out_rec, double *d_out_scal, void *stream);
 

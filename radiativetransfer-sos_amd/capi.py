@@ -65,7 +65,7 @@ def lib():
         L.sosgpu_os_solve.restype = i32
         L.sosgpu_os_solve.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sosgpu_aggregate.restype = i32
-        L.sosgpu_aggregate.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_aggregate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sosgpu_ctx_bytes.restype = C.c_size_t
         L.sosgpu_ctx_bytes.argtypes = [vp]
         L.sosgpu_os_flops.restype = i32

@@ -25,15 +25,41 @@ __global__ void k_aggregate(int nel, const int32_t *seg, const double *aik, cons
     out[(size_t)g * nel + e] = acc;
 }
 
+// Large single segments (throughput batches): bins are split into chunks accumulated serially and the chunk
+// partials are then summed in chunk order -- deterministic, same operation per term as SOS_AGGREGATE.F:401-403,
+// only the association of the outer sum differs from the strict serial order (<= 1e-16 relative).
+__global__ void k_aggregate_partial(int nel, int b0, int b1, int chunk, const double *aik, const double *rec, double *partial)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    const int c = blockIdx.y;
+    const int lo = b0 + c * chunk, hi = min(lo + chunk, b1);
+    double acc = 0.;
+#pragma unroll 8
+    for (int b = lo; b < hi; b++) acc = acc + aik[b] * rec[(size_t)b * nel + e];
+    partial[(size_t)c * nel + e] = acc;
+}
+
+__global__ void k_aggregate_final(int nel, int nchunk, const double *partial, double *out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    double acc = 0.;
+    for (int c = 0; c < nchunk; c++) acc = acc + partial[(size_t)c * nel + e];
+    out[e] = acc;
+}
+
 // out_scal[g][8]: sum aik*TDIFMUS, sum aik*EMOINS, sum aik*EPLUS, sum aik*exp(-TTOT_TRONC),
 //                 sum aik*exp(-TTOT_VRAI), sum aik*exp(-TAUOUT), sum aik, max norders
 __global__ void k_aggregate_scal(const int32_t *seg, const double *aik, const int32_t *norders,
                                  const double *flux, const double *scal, double *out)
 {
-    const int g = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    // 256 threads stride over the bins of the segment (serial within a thread), then a fixed-shape tree
+    // over the 256 partials: deterministic for a given segment size.
+    __shared__ double sm[256][8];
+    const int g = blockIdx.x, t = threadIdx.x;
     double a[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-    for (int b = seg[g]; b < seg[g + 1]; b++) {
+    for (int b = seg[g] + t; b < seg[g + 1]; b += 256) {
         const double w = aik[b];
         a[0] = a[0] + w * scal[4 * b + 0];
         a[1] = a[1] + w * flux[2 * b + 0];
@@ -44,15 +70,30 @@ __global__ void k_aggregate_scal(const int32_t *seg, const double *aik, const in
         a[6] = a[6] + w;
         a[7] = fmax(a[7], (double)norders[b]);
     }
-    for (int i = 0; i < 8; i++) out[8 * g + i] = a[i];
+    for (int i = 0; i < 8; i++) sm[t][i] = a[i];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (t < st)
+            for (int i = 0; i < 8; i++) sm[t][i] = (i == 7) ? fmax(sm[t][i], sm[t + st][i]) : sm[t][i] + sm[t + st][i];
+        __syncthreads();
+    }
+    if (t < 8) out[8 * g + t] = sm[0][t];
 }
 
 void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
-                      double *d_out_rec, double *d_out_scal, hipStream_t st)
+                      double *d_out_rec, double *d_out_scal, hipStream_t st, int nb_single, double *d_partial, int max_chunks)
 {
     const int nel = (cx.smax + 1) * 3 * cx.w;
-    dim3 grid((nel + 255) / 256, nseg);
-    k_aggregate<<<grid, 256, 0, st>>>(nel, d_seg, d_aik, d_rec, d_out_rec);
-    k_aggregate_scal<<<nseg, 64, 0, st>>>(d_seg, d_aik, d_norders, d_flux, d_scal, d_out_scal);
+    const int chunk = 64;
+    const int nchunk = (nb_single + chunk - 1) / chunk;
+    if (nseg == 1 && nb_single > 2 * chunk && d_partial && nchunk <= max_chunks) {
+        dim3 grid((nel + 255) / 256, nchunk);
+        k_aggregate_partial<<<grid, 256, 0, st>>>(nel, 0, nb_single, chunk, d_aik, d_rec, d_partial);
+        k_aggregate_final<<<(nel + 255) / 256, 256, 0, st>>>(nel, nchunk, d_partial, d_out_rec);
+    } else {
+        dim3 grid((nel + 255) / 256, nseg);
+        k_aggregate<<<grid, 256, 0, st>>>(nel, d_seg, d_aik, d_rec, d_out_rec);
+    }
+    k_aggregate_scal<<<nseg, 256, 0, st>>>(d_seg, d_aik, d_norders, d_flux, d_scal, d_out_scal);
 }

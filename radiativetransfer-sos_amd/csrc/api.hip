@@ -31,6 +31,7 @@ struct sosgpu_ctx {
     int nt_max_hint;
     double ind_surf;
     unsigned long long *phase;   // diagnostic phase-cycle buffer (sosgpu_debug_phase_buffer), else null
+    double *agg_partial;    // chunk partials of the large-batch aggregate
     double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
     size_t scratch_doubles;
 };
@@ -92,6 +93,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->scratch = nullptr;
     cx->scratch_doubles = 0;
     cx->phase = nullptr;
+    cx->agg_partial = nullptr;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -299,14 +301,27 @@ extern "C" int sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, cons
     return SOSGPU_OK;
 }
 
-extern "C" int sosgpu_aggregate(sosgpu_ctx *cx, int nseg, const int32_t *d_seg, const double *d_aik,
+extern "C" int sosgpu_aggregate(sosgpu_ctx *cx, int nb, int nseg, const int32_t *d_seg, const double *d_aik,
                                 const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
                                 double *d_out_rec, double *d_out_scal, void *stream)
 {
-    if (!cx || nseg < 1 || !d_seg || !d_aik || !d_rec || !d_norders || !d_flux || !d_scal || !d_out_rec || !d_out_scal)
+    if (!cx || nb < 1 || nseg < 1 || nseg > nb || !d_seg || !d_aik || !d_rec || !d_norders || !d_flux || !d_scal ||
+        !d_out_rec || !d_out_scal)
         return SOSGPU_E_ARG;
     HIPCHK(hipSetDevice(cx->device));
-    launch_aggregate(cx->d, nseg, d_seg, d_aik, d_rec, d_norders, d_flux, d_scal, d_out_rec, d_out_scal, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int max_chunks = 4096;
+    const int nb_single = (nseg == 1) ? nb : 0;      // one band: big batches use the chunked reduction
+    if (nb_single > 128 && !cx->agg_partial) {
+        const size_t nel = (size_t)(cx->d.smax + 1) * 3 * cx->d.w;
+        void *q = nullptr;
+        HIPCHK(hipMalloc(&q, nel * max_chunks * sizeof(double)));
+        cx->agg_partial = (double *)q;
+        cx->allocs.push_back(q);
+        cx->bytes += nel * max_chunks * sizeof(double);
+    }
+    launch_aggregate(cx->d, nseg, d_seg, d_aik, d_rec, d_norders, d_flux, d_scal, d_out_rec, d_out_scal, st,
+                     nb_single, cx->agg_partial, max_chunks);
     HIPCHK(hipGetLastError());
     return SOSGPU_OK;
 }

@@ -14,7 +14,7 @@ size_t sos_os_scratch_doubles(int n, int lpb);
 
 void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
-                      double *d_out_rec, double *d_out_scal, hipStream_t st);
+                      double *d_out_rec, double *d_out_scal, hipStream_t st, int nb_single, double *d_partial, int max_chunks);
 
 void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
                     int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st);

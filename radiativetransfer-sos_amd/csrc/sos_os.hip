@@ -160,11 +160,17 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 // BIG = true : the field, the attenuation table and the level vectors live in a per-bin HBM/L2 scratch
 //              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of
 //              16*CT levels staged through LDS, the formal solution streams the scratch with batched loads.
-template <int RTWH, int CT, bool BIG>
+// ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- tracks two extra levels per row.
+template <int RTWH, int CT, bool BIG, bool ZO>
 __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
     constexpr int COLS = 16 * CT;
+#ifdef SOS_SCAN_UNROLL_FORCE
+    constexpr int SU = SOS_SCAN_UNROLL_FORCE;
+#else
+    constexpr int SU = ZO ? 1 : (BIG ? 2 : 4);   // formal-solution unroll: bounded by the register budget of each variant
+#endif
     const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
     const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
     const int FS = BIG ? 2 * cx.kh : CS;   // level stride of the field storage
@@ -172,7 +178,9 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
     double *gnd = cbuf + COLS * CS;        // [3][N] down-going field at the ground, order ig-1
     double *i3s = gnd + 3 * N;             // [2N]   I3 of the I rows (flux integrals)
     double *red = i3s + 2 * N;             // [16]
-    double *sbase = BIG ? bn.scratch + (size_t)blockIdx.x * bn.scr_stride : red + 16;
+    double *lga = red + 16;                // [N] Gauss weights, [N] mu (LDS copies for the ground-reflection sums)
+    double *lmu = lga + N;
+    double *sbase = BIG ? bn.scratch + (size_t)blockIdx.x * bn.scr_stride : lmu + N;
     double *fld = BIG ? sbase : cbuf;      // [LPB][FS]   field / source, [level][+mu rows | -mu rows]
     double *att = BIG ? sbase + (size_t)LPB * FS : sbase;   // [LPB][N] exp(-dtau_i/mu_j), layer i = levels i..i+1
     double *dtau = att + (size_t)LPB * N;  // [LPB] each:
@@ -202,9 +210,9 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         const int b = blockIdx.x;
         const int nt = uniform_i32(bn.nt[b]);
         const int iborm = uniform_i32(bn.iborm[b]);
-        const int jout = uniform_i32(bn.jout ? bn.jout[b] : 0);
-        const double zz = uniform_f64(jout ? bn.zz[b] : 0.);
-        const int jlo = jout ? jout - 1 : -1, jhi = jout ? jout : -1;
+        const int jout = ZO ? uniform_i32(bn.jout ? bn.jout[b] : 0) : 0;
+        const double zz = ZO ? uniform_f64(jout ? bn.zz[b] : 0.) : 0.;
+        const int jlo = (ZO && jout) ? jout - 1 : -1, jhi = (ZO && jout) ? jout : -1;
         // shape guard (uniform): a malformed bin is flagged (norders = -1), never indexed out of bounds
         if (nt < 1 || nt >= LPB || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
             if (t == 0) bn.norders[b] = -1;
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         double *recb = bn.rec + (size_t)b * S1 * 3 * W;
 
         __syncthreads();
+        if (t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
         for (size_t i = t; i < (size_t)LPB * FS; i += 256) fld[i] = 0.;
         for (int i = t; i < LPB; i += 256) {
             const bool in = i <= nt;
@@ -239,12 +248,18 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         if (cx.imat_surf && active && up) {
             e_mu = exp(-htot / mu);
             e_lo = exp(-(htot - hh[0]) / mu);     // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
-            if (jout) { e_lo = exp(-(htot - hh[jlo]) / mu); e_hi = exp(-(htot - hh[jhi]) / mu); }
+            if (ZO && jout) { e_lo = exp(-(htot - hh[jlo]) / mu); e_hi = exp(-(htot - hh[jhi]) / mu); }
         }
         __syncthreads();
 
         // per-thread formal solution of its row, in place over the source held in fld (SOS_INTEGR_EPOPT,
-        // SOS_OS.F:2279-2354).  bcv = value at the ground for up-going rows.
+        // SOS_OS.F:2279-2354).  bcv = value at the ground for up-going rows.  With t = exp(-dtau/|mu|) and the
+        // source linear in tau on the layer, both directions reduce to the same three-term recurrence
+        //     X_i = t X_n + p S_i + w S_n,   w = ((1-t)|mu| - t dtau)/dtau,  p = (1-t) - w
+        // (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), which is algebraically
+        // the reference update X t + (1-t)(a mu + b) -/+ a t dtau.  Up- and down-going rows share ONE instruction
+        // stream (per-lane level index), so wavefronts holding both kinds of rows do not run the loop twice, and
+        // only one FMA per level sits on the dependent chain.
         double xb, xlo = 0., xhi = 0.;
         auto scan_row = [&](double bcv) {
             if (!active) { xb = 0.; return; }
@@ -252,43 +267,29 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             __builtin_amdgcn_s_setprio(SOS_SCAN_PRIO);
 #endif
             const double *arow = att + jj;
-            if (up) {
-                double z = bcv;
-                double snext = fld[(size_t)nt * FS + rl];
-                fld[(size_t)nt * FS + rl] = z;
-                if (jhi == nt) xhi = z;
-SOS_UNROLL(SOS_SCAN_UNROLL)
-                for (int i = nt - 1; i >= 0; --i) {   // in BIG mode the unrolled body batches the scratch loads
-                    const double a_t = arow[i * N], dt = dtau[i];
-                    const double bq = fld[(size_t)i * FS + rl];
-                    const double a = (snext - bq) * idtau[i];
-                    z = z * a_t + (1.0 - a_t) * (a * mu + bq) - a * (a_t * dt);
-                    fld[(size_t)i * FS + rl] = z;
-                    snext = bq;
-                    if (i == jlo) xlo = z;
-                    if (i == jhi) xhi = z;
-                }
-                xb = z;
-            } else {
-                double z = 0.;
-                double sprev = fld[rl];
-                fld[rl] = 0.;
-                if (jlo == 0) xlo = 0.;
-                const double rmuk = -mu;
-SOS_UNROLL(SOS_SCAN_UNROLL)
-                for (int i = 1; i <= nt; ++i) {
-                    const double a_t = arow[(i - 1) * N], dt = dtau[i - 1];
-                    const double bq = fld[(size_t)i * FS + rl];
-                    const double a = (bq - sprev) * idtau[i - 1];
-                    z = z * a_t + (1.0 - a_t) * (a * rmuk + bq) + a * (a_t * dt);
-                    fld[(size_t)i * FS + rl] = z;
-                    sprev = bq;
-                    if (i == jlo) xlo = z;
-                    if (i == jhi) xhi = z;
-                }
-                xb = z;
-                gnd[c * N + jj] = z;
+            const int i0 = up ? nt : 0;                 // level the ray starts from
+            const int di = up ? -1 : 1;
+            double z = up ? bcv : 0.;
+            double sn = fld[(size_t)i0 * FS + rl];      // source at the level the ray comes from
+            fld[(size_t)i0 * FS + rl] = z;
+            if (ZO) { if (i0 == jlo) xlo = z; if (i0 == jhi) xhi = z; }
+            int i = i0;
+#pragma unroll SU
+            for (int k = 0; k < nt; ++k) {
+                const int li = up ? i - 1 : i;          // layer between levels li and li+1
+                i += di;
+                const double a_t = arow[li * N], dt = dtau[li], idt = idtau[li];
+                const double si = fld[(size_t)i * FS + rl];
+                const double omt = 1.0 - a_t;
+                const double w = (omt * mu - a_t * dt) * idt;
+                const double pq = omt - w;
+                z = z * a_t + (pq * si + w * sn);
+                fld[(size_t)i * FS + rl] = z;
+                sn = si;
+                if (ZO) { if (i == jlo) xlo = z; if (i == jhi) xhi = z; }
             }
+            xb = z;
+            if (!up) gnd[c * N + jj] = z;
 #ifdef SOS_SCAN_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -311,7 +312,7 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                 if (c == 0 && cx.ro != 0. && s == 0) {
                     double lsol = 0.;
 #pragma unroll 1
-                    for (int j = 0; j < N; j++) lsol = lsol + cx.ga[j] * gnd[j] * cx.mu[j];
+                    for (int j = 0; j < N; j++) lsol = lsol + lga[j] * gnd[j] * lmu[j];
                     lsol = 2 * lsol * cx.ro;
                     v = lsol; xr = lsol;
                 }
@@ -324,7 +325,7 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                     for (int j = 0; j < N; j++) {
                         double q0 = r0[j], q1 = r1[j], q2 = r2[j];
                         if (!cx.ipolar) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }   // SOS_OS.F:928-941
-                        acc2 = acc2 + cx.ga[j] * (gnd[j] * q0 + gnd[N + j] * q1 + gnd[2 * N + j] * q2);
+                        acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[N + j] * q1 + gnd[2 * N + j] * q2);
                     }
                     v = acc2 * (2 / mu) + xr;
                 }
@@ -369,10 +370,10 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
             if (cx.imat_surf && active && up) {                                      // SOS_OS.F:1062-1084
                 rii = e_mu * dirterm;
                 riilo = e_lo * dirterm;
-                riihi = e_hi * dirterm;
+                if (ZO) riihi = e_hi * dirterm;
             }
             double i3 = xb, a1 = 0., d1 = xb, g1 = 0.;                               // SOS_OS.F:1094-1137
-            double i3lo = xlo, dlo = xlo, i3hi = xhi, dhi = xhi;
+            double i3lo = ZO ? xlo : 0., dlo = i3lo, i3hi = ZO ? xhi : 0., dhi = i3hi;
             __syncthreads();
             bc = ground_bc();
             PH(5);
@@ -453,12 +454,12 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                 PH(5);
                 if (ig != 2 && !(y1 > cx.thr_cv)) {                                  // SOS_OS.F:1293-1315
                     i3 = i3 + queue_term(d1, g1);
-                    i3lo = i3lo + queue_term(dlo, xlo);
-                    i3hi = i3hi + queue_term(dhi, xhi);
+                    if (ZO) { i3lo = i3lo + queue_term(dlo, xlo); i3hi = i3hi + queue_term(dhi, xhi); }
                     break;
                 }
-                a1 = d1; d1 = g1; dlo = xlo; dhi = xhi;                              // SOS_OS.F:1323-1363
-                i3 = i3n; i3lo = i3lo + xlo; i3hi = i3hi + xhi;
+                a1 = d1; d1 = g1;                                                    // SOS_OS.F:1323-1363
+                i3 = i3n;
+                if (ZO) { dlo = xlo; dhi = xhi; i3lo = i3lo + xlo; i3hi = i3hi + xhi; }
                 if (!(y2 > cx.thr_val)) break;                                       // SOS_OS.F:1370
                 if (!(y3 > cx.thr_sum)) break;                                       // SOS_OS.F:1389
                 if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
@@ -466,7 +467,10 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
             // SOS_OS.F:1421-1439.  The record is built from I3OUT (minus RIIOUT at the output level), the stop
             // tests and fluxes from I3 (minus RII): the two differ by exp(H(0)/mu) on the direct term.
             double i3out0 = i3;
-            if (cx.imat_surf && active && up) { i3out0 = i3 - riilo; i3 = i3 - rii; i3lo = i3lo - riilo; i3hi = i3hi - riihi; }
+            if (cx.imat_surf && active && up) {
+                i3out0 = i3 - riilo; i3 = i3 - rii;
+                if (ZO) { i3lo = i3lo - riilo; i3hi = i3hi - riihi; }
+            }
 
             if (s == 0) {                                                            // SOS_OS.F:1447-1456
                 if (active && c == 0) i3s[d] = i3;
@@ -474,8 +478,8 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
                 if (t == 0) {
                     double em = 0., ep = 0.;
                     for (int j = 0; j < N; j++) {
-                        em = em + cx.mu[j] * cx.ga[j] * i3s[N + j];
-                        ep = ep + cx.mu[j] * cx.ga[j] * i3s[j];
+                        em = em + lmu[j] * lga[j] * i3s[N + j];
+                        ep = ep + lmu[j] * lga[j] * i3s[j];
                     }
                     bn.flux[2 * b] = em * 2 / cx.mus;
                     bn.flux[2 * b + 1] = ep * 2 / cx.mus;
@@ -485,7 +489,7 @@ SOS_UNROLL(SOS_SCAN_UNROLL)
             i4 = i4 + coef * i3;
             i5 = i5 + coef * i3 * sign;
             if (active) {                                                            // SOS_OS.F:1484-1534,1572
-                const double outv = jout ? ((1 - zz) * i3lo + zz * i3hi) : i3out0;
+                const double outv = (ZO && jout) ? ((1 - zz) * i3lo + zz * i3hi) : i3out0;
                 recb[(size_t)s * 3 * W + recoff] = outv;
                 if (up && jj == 0) recb[(size_t)s * 3 * W + c * W + N] = 0.;
             }
@@ -517,7 +521,7 @@ static size_t lds_bytes_for(int n, int ct, bool big)
 {
     const int cols = 16 * ct;
     const int kh = sos_round_up(3 * n, 8);
-    size_t dbl = (size_t)cols * (2 * kh + 2) + 3 * n + 2 * n + 16;
+    size_t dbl = (size_t)cols * (2 * kh + 2) + 3 * n + 2 * n + 16 + 2 * n;
     if (!big) dbl += (size_t)cols * n + 7 * cols;
     return dbl * sizeof(double);
 }
@@ -548,10 +552,10 @@ size_t sos_os_scratch_doubles(int n, int lpb)
     return (size_t)lpb * (2 * kh) + (size_t)lpb * n + 7 * (size_t)lpb;
 }
 
-template <int RTWH, int CT, bool BIG>
+template <int RTWH, int CT, bool BIG, bool ZO>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
-    auto kern = k_sos_os<RTWH, CT, BIG>;
+    auto kern = k_sos_os<RTWH, CT, BIG, ZO>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -2;
     const int grid = bn.nb;
@@ -567,7 +571,10 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     if (rc) return rc;
     if (cx.rtph != 4 * rtw) return SOSGPU_E_UNSUPPORTED;
     if (big && (!bn.scratch || bn.lpb < nt_max + 1)) return SOSGPU_E_UNSUPPORTED;
-#define V(R, C, B) if (rtw == R && ct == C && big == B) return launch_variant<R, C, B>(cx, bn, lds, st);
+    const int zo = bn.jout != nullptr;
+#define V(R, C, B)                                                                        \
+    if (rtw == R && ct == C && big == B)                                                  \
+        return zo ? launch_variant<R, C, B, true>(cx, bn, lds, st) : launch_variant<R, C, B, false>(cx, bn, lds, st);
     V(1, 2, 0) V(2, 2, 0) V(3, 2, 0) V(4, 2, 0)
     V(1, 4, 0) V(2, 4, 0) V(3, 4, 0)
     V(1, 2, 1) V(2, 2, 1) V(3, 2, 1) V(4, 2, 1)

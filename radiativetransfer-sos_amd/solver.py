@@ -163,7 +163,7 @@ class SosContext:
         scal_t = torch.zeros((nb, 4), dtype=torch.float64, device=d) if scal is None else _dev_f64(scal, d)
         o_rec = torch.empty((nseg, self.smax + 1, 3, self.w), dtype=torch.float64, device=d)
         o_scal = torch.empty((nseg, 8), dtype=torch.float64, device=d)
-        capi.check(capi.lib().sosgpu_aggregate(self._h, nseg, _ptr(seg_t), _ptr(aik_t), _ptr(out["rec"]),
+        capi.check(capi.lib().sosgpu_aggregate(self._h, nb, nseg, _ptr(seg_t), _ptr(aik_t), _ptr(out["rec"]),
                                                _ptr(out["norders"]), _ptr(out["flux"]), _ptr(scal_t),
                                                _ptr(o_rec), _ptr(o_scal), self._stream()), "sosgpu_aggregate")
         return o_rec, o_scal

@@ -89,7 +89,9 @@ def test_sos_proc_vs_reference(gpu_pkg, name):
             tol = 1e-9 * np.abs(exp) + 1e-12 * scale
             assert np.all(np.abs(got - exp) <= tol), (nm, np.abs(got - exp).max())
         elif nm.startswith("sca_ang"):
-            assert np.allclose(got, exp, rtol=0, atol=1e-9), nm
+            # acos is ill-conditioned at exact forward/backward scattering: compare cosines tightly, angles loosely
+            assert np.allclose(np.cos(np.radians(got)), np.cos(np.radians(exp)), rtol=0, atol=1e-13), nm
+            assert np.allclose(got, exp, rtol=0, atol=1e-5), nm
         elif nm.startswith(("pol_ang", "pol_rate")):
             # angle/rate of polarisation are ill-conditioned where Q,U ~ 0: compare where the polarised radiance is significant
             lp = g["l_pol_up"] if nm.endswith("up") else g["l_pol_down"]
