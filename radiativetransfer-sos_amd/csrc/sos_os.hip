@@ -37,12 +37,42 @@
 #define SOS_PRAGMA(x) _Pragma(#x)
 #define SOS_UNROLL(n) SOS_PRAGMA(unroll n)
 
+#ifdef SOS_DPP_REDUCE
+// max over the 64 lanes: four DPP steps inside each row of 16 lanes (no LDS crossbar traffic), then the four row
+// results are read with v_readlane.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xf, 0xf, false);
+    return r.d;
+}
+__device__ __forceinline__ double lane_f64(double v, int lane)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_f64<0x141>(v));   // row_half_mirror
+    v = fmax(v, dpp_f64<0x140>(v));   // row_mirror
+    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
+}
+#else
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+#endif
 
 // Force a value the whole wave agrees on into scalar registers, so that the loop exits it decides are
 // uniform branches (keeps s / ig / operator pointers in SGPRs instead of per-lane VGPRs).
@@ -191,6 +221,12 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
     double *fco = ch + LPB;
     double *hh = fco + LPB;
 
+#ifdef SOS_STATIC_PRIO
+    // Two workgroups share a CU (one wave of each per SIMD).  Give the one whose LDS allocation starts at 0 a
+    // higher static priority: it wins the matrix pipe whenever both want it, so the pair settles in anti-phase
+    // (one contracting while the other runs its formal solution) instead of sharing the pipe and then idling it.
+    if ((__builtin_amdgcn_s_getreg(0x3806) & 0xff) == 0) __builtin_amdgcn_s_setprio(SOS_STATIC_PRIO);
+#endif
     // thread -> state row: t < 3N up-going (+mu), 3N <= t < 6N down-going; kk = c*N + jj in both halves
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool active = t < R6;
@@ -273,20 +309,26 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             double sn = fld[(size_t)i0 * FS + rl];      // source at the level the ray comes from
             fld[(size_t)i0 * FS + rl] = z;
             if (ZO) { if (i0 == jlo) xlo = z; if (i0 == jhi) xhi = z; }
-            int i = i0;
+            // software pipeline: the operands of level k+1 are loaded BEFORE the store of level k (the compiler
+            // cannot hoist them itself across the in-place store), so the LDS/L2 latency overlaps the arithmetic
+            int i = i0 + di;
+            int li = up ? i0 - 1 : i0;                  // layer between levels li and li+1
+            double a_t = arow[li * N], dt = dtau[li], idt = idtau[li];
+            double si = fld[(size_t)i * FS + rl];
 #pragma unroll SU
             for (int k = 0; k < nt; ++k) {
-                const int li = up ? i - 1 : i;          // layer between levels li and li+1
-                i += di;
-                const double a_t = arow[li * N], dt = dtau[li], idt = idtau[li];
-                const double si = fld[(size_t)i * FS + rl];
+                const int in = (k + 1 < nt) ? i + di : i;        // next level (clamped on the last trip)
+                const int lin = (k + 1 < nt) ? li + di : li;
+                const double a_n = arow[lin * N], dt_n = dtau[lin], idt_n = idtau[lin];
+                const double si_n = fld[(size_t)in * FS + rl];
                 const double omt = 1.0 - a_t;
                 const double w = (omt * mu - a_t * dt) * idt;
                 const double pq = omt - w;
                 z = z * a_t + (pq * si + w * sn);
                 fld[(size_t)i * FS + rl] = z;
-                sn = si;
                 if (ZO) { if (i == jlo) xlo = z; if (i == jhi) xhi = z; }
+                sn = si; si = si_n; a_t = a_n; dt = dt_n; idt = idt_n;
+                i = in; li = lin;
             }
             xb = z;
             if (!up) gnd[c * N + jj] = z;
