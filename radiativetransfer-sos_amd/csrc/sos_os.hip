@@ -99,20 +99,28 @@ __device__ __forceinline__ void block_max3(double &a, double &b, double &c, doub
     __syncthreads();
 }
 
-// one term of SOS_PARAM_CONV (SOS_OS.F:3434-3453)
-__device__ __forceinline__ double conv_term(double a, double d, double g, double x3)
+// FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak rates): every f64 VALU
+// instruction issued while the co-resident workgroup is contracting waits for a 64-cycle MFMA slot.  The stop
+// tests are therefore evaluated WITHOUT divisions and WITHOUT floating-point reductions: "max_k |y_k| > thr" is
+// the same decision as "exists k: |num_k| > thr |den_k|", reduced with one __syncthreads_or of predicate bits.
+//
+// SOS_PARAM_CONV (SOS_OS.F:3434-3453): y = ((g/d - d/a) / (1 - g/d)^2) (g/x3) = (g a - d^2) d g / (a (d-g)^2 x3)
+// for a, d, x3 != 0.  (Differs from the quotient form only by rounding at the 1e-16 level of a 1e-5 threshold;
+// operands below ~1e-77 underflow in the products and are then ignored -- they are 1e-60 of the radiance scale.)
+__device__ __forceinline__ bool conv_exceeds(double a, double d, double g, double x3, double thr)
 {
     if (a != 0.0 && d != 0.0 && x3 != 0.0) {
-        const double gd = g / d;
-        const double y = ((gd - d / a) / ((1 - gd) * (1 - gd)) * (g / x3));
-        return fabs(y);
+        const double dg = d - g;
+        const double num = (g * a - d * d) * (d * g);
+        const double den = (a * x3) * (dg * dg);
+        return fabs(num) > thr * fabs(den);
     }
-    return 0.;
+    return false;
 }
-// SOS_AJOUT_QUEUE (SOS_OS.F:3959-3975)
+// SOS_AJOUT_QUEUE (SOS_OS.F:3959-3975): g / (1 - g/d) = g d / (d - g)
 __device__ __forceinline__ double queue_term(double d, double g)
 {
-    return (d == 0.) ? 0. : g / (1 - g / d);
+    return (d == 0.) ? 0. : (g * d) / (d - g);
 }
 
 // Source contraction in the parity-decomposed form (sos_common.h): for both half systems
@@ -135,10 +143,12 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll 1
     for (int pass = pass_lo; pass < pass_hi; pass++) {
         const v2d *ap = reinterpret_cast<const v2d *>(pass ? mp1 : mp0) + ((size_t)(wv * RTWH) * ks2h) * 64 + lane;
-        const double *scale = pass ? scale1 : scale0;
+        // pass 0 (aerosol): the column scale XDEL is applied to the accumulators once, after the loop;
+        // pass 1 (molecular, s <= 2, accumulating on top): the B fragments are scaled by YDEL on the fly.
+        const bool scale_b = pass != 0;
         double sc[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) sc[ct] = scale[ct * 16 + (lane & 15)];
+        for (int ct = 0; ct < CT; ct++) sc[ct] = (pass ? scale1 : scale0)[ct * 16 + (lane & 15)];
         v2d a_cur[2][RTWH], a_nxt[2][RTWH];
 #pragma unroll
         for (int sy = 0; sy < 2; sy++)
@@ -152,17 +162,21 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
                     for (int rt = 0; rt < RTWH; rt++) a_nxt[sy][rt] = ap[sy * sys_stride + rt * rts + (size_t)(m + 1) * 64];
             }
-            // g = +1 for I,Q rows (kk < 2N), -1 for U rows; the two K indices of this lane are 8m+2q and 8m+2q+1
+            // g = +1 for I,Q rows (kk < 2N), -1 for U rows: applied as a sign-bit flip (integer op, keeps the FP64
+            // datapath for the MFMAs); the two K indices of this lane are 8m+2q and 8m+2q+1
             const int kk0 = 8 * m + 2 * (lane >> 4);
-            const double g0 = (kk0 < n2) ? 1. : -1., g1 = (kk0 + 1 < n2) ? 1. : -1.;
+            const unsigned long long f0 = (kk0 < n2) ? 0ull : 0x8000000000000000ull;
+            const unsigned long long f1 = (kk0 + 1 < n2) ? 0ull : 0x8000000000000000ull;
             v2d ba[CT], bb[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const v2d xp = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
                 const v2d xm = *reinterpret_cast<const v2d *>(bp[ct] + KH + 8 * m);
-                const double m0 = g0 * xm.x, m1 = g1 * xm.y;
-                ba[ct].x = (xp.x + m0) * sc[ct]; ba[ct].y = (xp.y + m1) * sc[ct];
-                bb[ct].x = (xp.x - m0) * sc[ct]; bb[ct].y = (xp.y - m1) * sc[ct];
+                const double m0 = __longlong_as_double(__double_as_longlong(xm.x) ^ f0);
+                const double m1 = __longlong_as_double(__double_as_longlong(xm.y) ^ f1);
+                ba[ct].x = xp.x + m0; ba[ct].y = xp.y + m1;
+                bb[ct].x = xp.x - m0; bb[ct].y = xp.y - m1;
+                if (scale_b) { ba[ct].x *= sc[ct]; ba[ct].y *= sc[ct]; bb[ct].x *= sc[ct]; bb[ct].y *= sc[ct]; }
             }
 #pragma unroll
             for (int rt = 0; rt < RTWH; rt++)
@@ -183,6 +197,14 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
                 for (int rt = 0; rt < RTWH; rt++) a_cur[sy][rt] = a_nxt[sy][rt];
         }
+        if (!scale_b) {     // XDEL of the output level: every accumulator register of a lane belongs to one column
+#pragma unroll
+            for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] *= sc[ct];
+        }
     }
 }
 
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
 #ifdef SOS_SCAN_UNROLL_FORCE
     constexpr int SU = SOS_SCAN_UNROLL_FORCE;
 #else
-    constexpr int SU = ZO ? 1 : (BIG ? 2 : 4);   // formal-solution unroll: bounded by the register budget of each variant
+    constexpr int SU = (ZO || BIG) ? 1 : 4;      // formal-solution unroll: bounded by the register budget of each variant
 #endif
     const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
     const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
@@ -220,6 +242,9 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
     double *ch = ydel + LPB;
     double *fco = ch + LPB;
     double *hh = fco + LPB;
+    // formal-solution coefficients p, w per (layer, direction): per-bin table in HBM/L2 (no LDS left for them)
+    double *pqt = bn.tabs + (size_t)blockIdx.x * bn.tab_stride;
+    double *wt = pqt + (size_t)LPB * N;
 
 #ifdef SOS_STATIC_PRIO
     // Two workgroups share a CU (one wave of each per SIMD).  Give the one whose LDS allocation starts at 0 a
@@ -277,7 +302,13 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             if (i <= nt && xdel[i] != 0.) aer_l = 1;
         }
         const int has_aer = uniform_i32(__syncthreads_or(aer_l));
-        for (int i = t; i < nt * N; i += 256) att[i] = exp(-dtau[i / N] / cx.mu[i % N]);      // SOS_OS.F:2291,2335
+        for (int i = t; i < nt * N; i += 256) {                                               // SOS_OS.F:2291,2335
+            const int li = i / N, j = i % N;
+            const double a_t = exp(-dtau[li] / cx.mu[j]);
+            const double omt = 1.0 - a_t;
+            const double w = (omt * cx.mu[j] - a_t * dtau[li]) * idtau[li];
+            att[i] = a_t; wt[i] = w; pqt[i] = omt - w;
+        }
         // bin-constant exponentials of the ground boundary terms (SOS_OS.F:979,985,1068-1077)
         const double e_sun = uniform_f64(exp(-htot / cx.mus));
         double e_mu = 0., e_lo = 0., e_hi = 0.;
@@ -309,26 +340,28 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             double sn = fld[(size_t)i0 * FS + rl];      // source at the level the ray comes from
             fld[(size_t)i0 * FS + rl] = z;
             if (ZO) { if (i0 == jlo) xlo = z; if (i0 == jhi) xhi = z; }
-            // software pipeline: the operands of level k+1 are loaded BEFORE the store of level k (the compiler
-            // cannot hoist them itself across the in-place store), so the LDS/L2 latency overlaps the arithmetic
+            // software pipeline: coefficients are fetched two levels ahead (L2 latency), the source one level ahead,
+            // all BEFORE the in-place store of the current level (the compiler cannot hoist them across it itself)
+            const double *prow = pqt + jj, *wrow = wt + jj;
+            const int lstep = di;                                   // layer index moves with the ray
             int i = i0 + di;
-            int li = up ? i0 - 1 : i0;                  // layer between levels li and li+1
-            double a_t = arow[li * N], dt = dtau[li], idt = idtau[li];
+            int li = up ? i0 - 1 : i0;                              // layer between levels li and li+1
+            int li2 = (nt > 1) ? li + lstep : li;
+            double a0 = arow[li * N], p0 = prow[li * N], w0 = wrow[li * N];
+            double a1c = arow[li2 * N], p1 = prow[li2 * N], w1 = wrow[li2 * N];
             double si = fld[(size_t)i * FS + rl];
 #pragma unroll SU
             for (int k = 0; k < nt; ++k) {
-                const int in = (k + 1 < nt) ? i + di : i;        // next level (clamped on the last trip)
-                const int lin = (k + 1 < nt) ? li + di : li;
-                const double a_n = arow[lin * N], dt_n = dtau[lin], idt_n = idtau[lin];
+                const int in = (k + 1 < nt) ? i + di : i;           // next level (clamped on the last trips)
+                const int li3 = (k + 2 < nt) ? li2 + lstep : li2;
+                const double a2 = arow[li3 * N], p2 = prow[li3 * N], w2 = wrow[li3 * N];
                 const double si_n = fld[(size_t)in * FS + rl];
-                const double omt = 1.0 - a_t;
-                const double w = (omt * mu - a_t * dt) * idt;
-                const double pq = omt - w;
-                z = z * a_t + (pq * si + w * sn);
+                z = z * a0 + (p0 * si + w0 * sn);
                 fld[(size_t)i * FS + rl] = z;
                 if (ZO) { if (i == jlo) xlo = z; if (i == jhi) xhi = z; }
-                sn = si; si = si_n; a_t = a_n; dt = dt_n; idt = idt_n;
-                i = in; li = lin;
+                sn = si; si = si_n;
+                a0 = a1c; p0 = p1; w0 = w1; a1c = a2; p1 = p2; w1 = w2;
+                i = in; li2 = li3;
             }
             xb = z;
             if (!up) gnd[c * N + jj] = z;
@@ -487,14 +520,18 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                 PH(1);
                 g1 = xb;
                 const double i3n = i3 + g1;
-                double y1 = (ig != 2) ? conv_term(a1, d1, g1, i3) : 0.;              // SOS_PARAM_CONV
-                double y2 = fabs(g1);                                                // SOS_ARRET_DIFFUS_1
-                double y3 = (i3n != 0.0) ? fabs(g1 / i3n) : 0.;                      // SOS_ARRET_DIFFUS_2
-                block_max3(y1, y2, y3, red);
+                int pm = 0;
+                if (active) {
+                    if (ig != 2 && conv_exceeds(a1, d1, g1, i3, cx.thr_cv)) pm |= 1;     // SOS_PARAM_CONV
+                    const double ag = fabs(g1);
+                    if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
+                    if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
+                }
+                pm = uniform_i32(__syncthreads_or(pm));
                 PH(4);
                 bc = ground_bc();
                 PH(5);
-                if (ig != 2 && !(y1 > cx.thr_cv)) {                                  // SOS_OS.F:1293-1315
+                if (ig != 2 && !(pm & 1)) {                                          // SOS_OS.F:1293-1315
                     i3 = i3 + queue_term(d1, g1);
                     if (ZO) { i3lo = i3lo + queue_term(dlo, xlo); i3hi = i3hi + queue_term(dhi, xhi); }
                     break;
@@ -502,8 +539,8 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                 a1 = d1; d1 = g1;                                                    // SOS_OS.F:1323-1363
                 i3 = i3n;
                 if (ZO) { dlo = xlo; dhi = xhi; i3lo = i3lo + xlo; i3hi = i3hi + xhi; }
-                if (!(y2 > cx.thr_val)) break;                                       // SOS_OS.F:1370
-                if (!(y3 > cx.thr_sum)) break;                                       // SOS_OS.F:1389
+                if (!(pm & 2)) break;                                                // SOS_OS.F:1370
+                if (!(pm & 4)) break;                                                // SOS_OS.F:1389
                 if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
             }
             // SOS_OS.F:1421-1439.  The record is built from I3OUT (minus RIIOUT at the output level), the stop
@@ -537,14 +574,14 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             }
             if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
             nord = s + 1;
-            double z1 = 0., z2 = 0., z3 = 0.;                                        // SOS_ARRET_FOURIER
+            int pf = 0;                                                              // SOS_ARRET_FOURIER
             if (active) {
-                if (i4 != 0.0) z1 = fabs(i3 / i4);
-                if (i5 != 0.0) z2 = fabs(i3 / i5);
+                const double a3 = fabs(i3);
+                if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf = 1;
             }
-            block_max3(z1, z2, z3, red);
+            pf = uniform_i32(__syncthreads_or(pf));
             PH(6);
-            if (!(fmax(z1, z2) > cx.thr_sf)) break;                                  // SOS_OS.F:1585
+            if (!pf) break;                                                          // SOS_OS.F:1585
         }
         // orders not run: zero records and counts
         for (int i = t + nord * 3 * W; i < S1 * 3 * W; i += 256) recb[i] = 0.;
