@@ -37,43 +37,6 @@
 #define SOS_PRAGMA(x) _Pragma(#x)
 #define SOS_UNROLL(n) SOS_PRAGMA(unroll n)
 
-#ifdef SOS_DPP_REDUCE
-// max over the 64 lanes: four DPP steps inside each row of 16 lanes (no LDS crossbar traffic), then the four row
-// results are read with v_readlane.  The result is wave-uniform.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v)
-{
-    union { double d; int i[2]; } u, r;
-    u.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xf, 0xf, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xf, 0xf, false);
-    return r.d;
-}
-__device__ __forceinline__ double lane_f64(double v, int lane)
-{
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
-    return u.d;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-    v = fmax(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
-    v = fmax(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
-    v = fmax(v, dpp_f64<0x141>(v));   // row_half_mirror
-    v = fmax(v, dpp_f64<0x140>(v));   // row_mirror
-    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
-}
-#else
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-#endif
-
 // Force a value the whole wave agrees on into scalar registers, so that the loop exits it decides are
 // uniform branches (keeps s / ig / operator pointers in SGPRs instead of per-lane VGPRs).
 __device__ __forceinline__ double uniform_f64(double v)
@@ -86,17 +49,19 @@ __device__ __forceinline__ double uniform_f64(double v)
 }
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// max over the workgroup of three values at once (red: 12 doubles of LDS); contains two barriers
-__device__ __forceinline__ void block_max3(double &a, double &b, double &c, double *red)
+// bitwise OR over the workgroup of up to 3 predicate bits (red: 4 ints of LDS); two barriers, no FP64 work.
+// (__syncthreads_or only returns a logical OR.)
+__device__ __forceinline__ int block_or_bits(int bits, int *red)
 {
-    a = wave_max(a); b = wave_max(b); c = wave_max(c);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[w * 3] = a; red[w * 3 + 1] = b; red[w * 3 + 2] = c; }
+    int w = 0;
+    if (__ballot(bits & 1)) w |= 1;
+    if (__ballot(bits & 2)) w |= 2;
+    if (__ballot(bits & 4)) w |= 4;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    a = uniform_f64(fmax(fmax(red[0], red[3]), fmax(red[6], red[9])));
-    b = uniform_f64(fmax(fmax(red[1], red[4]), fmax(red[7], red[10])));
-    c = uniform_f64(fmax(fmax(red[2], red[5]), fmax(red[8], red[11])));
+    const int r = red[0] | red[1] | red[2] | red[3];
     __syncthreads();
+    return uniform_i32(r);
 }
 
 // FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak rates): every f64 VALU
@@ -527,7 +492,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                     if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
                     if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
                 }
-                pm = uniform_i32(__syncthreads_or(pm));
+                pm = block_or_bits(pm, reinterpret_cast<int *>(red));
                 PH(4);
                 bc = ground_bc();
                 PH(5);
@@ -579,7 +544,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                 const double a3 = fabs(i3);
                 if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf = 1;
             }
-            pf = uniform_i32(__syncthreads_or(pf));
+            pf = block_or_bits(pf, reinterpret_cast<int *>(red));
             PH(6);
             if (!pf) break;                                                          // SOS_OS.F:1585
         }
