@@ -152,12 +152,14 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     const size_t per = (size_t)2 * d.rtph * d.ks2h * 128;
     if ((rc = dev_alloc(cx, &d.prt, (size_t)(d.smax + 1) * 3 * (B + 1) * d.w)) ||
         (rc = dev_alloc(cx, &d.mp_aer, (size_t)(d.smax + 1) * per)) ||
-        (rc = dev_alloc(cx, &d.mp_ray, (size_t)3 * per)) ||
+        (rc = dev_alloc(cx, &d.mp_vt, (size_t)3 * d.ks2h * 128)) ||
+        (rc = dev_alloc(cx, &d.mp_uf, (size_t)3 * d.rtph * 64)) ||
         (rc = dev_alloc(cx, &d.sv, (size_t)(d.smax + 1) * 4 * d.kp))) {
         sosgpu_destroy(cx);
         return rc;
     }
-    hipMemset(d.mp_ray, 0, 3 * per * sizeof(double));
+    hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double));
+    hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double));
     if (hipEventCreate(&cx->ev0) != hipSuccess || hipEventCreate(&cx->ev1) != hipSuccess) {
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;

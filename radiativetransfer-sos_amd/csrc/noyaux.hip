@@ -177,7 +177,57 @@ __global__ void k_pack(SosDev cx)
     const int H = 3 * cx.n;
     const bool in = row < H && col < H;
     cx.mp_aer[(size_t)s * 2 * per + e] = in ? half_element<false>(cx, s, sys, row, col) : 0.;
-    if (s <= 2) cx.mp_ray[(size_t)s * 2 * per + e] = in ? half_element<true>(cx, s, sys, row, col) : 0.;
+}
+
+// Molecular (Rayleigh) part of the source operator for s <= 2 (SOS_OS.F:2859-2876).  Its kernels are single
+// Legendre terms (l = 2, plus beta0 at s = 0), so in the parity basis the operator is EXACTLY rank <= 4 and acts on
+// one half system only (A for even s, B for odd s; the other half is identically zero):
+//     M_ray = U V^T,   V^T [4 x 3N] (rows: I-, Q-, U-row projections, beta0 sum),   U [3N x 4]
+//   V^T[0] = w/2 ( b2 P,  g2 R, -g2 T)   -> times P(k) on the I rows
+//   V^T[1] = w/2 ( g2 P,  a2 R, -a2 T)   -> times R(k) on the Q rows
+//   V^T[2] = w/2 (-g2 P, -a2 R,  a2 T)   -> times T(k) on the U rows
+//   V^T[3] = w/2 ( b0, 0, 0)             -> times 1 on the I rows (s = 0)
+// with P,R,T = P^s_2, R^s_2, T^s_2 at the Gauss nodes.  Packed as MFMA A operands:
+//   vt[(m*64 + lane)*2 + e] = V^T[lane&15][8m + 2(lane>>4) + e]   (projection, K = 3N)
+//   uf[rt*64 + lane]        = U[rt*16 + (lane&15)][lane>>4]       (expansion, K = 4)
+__global__ void k_pack_ray(SosDev cx)
+{
+    const int s = blockIdx.x;                 // 0..2
+    const int N = cx.n, W = cx.w, B = cx.os_nb;
+    const double *P = cx.prt + ((size_t)(s * 3 + 0) * (B + 1) + 2) * W + N;   // l = 2
+    const double *R = cx.prt + ((size_t)(s * 3 + 1) * (B + 1) + 2) * W + N;
+    const double *T = cx.prt + ((size_t)(s * 3 + 2) * (B + 1) + 2) * W + N;
+    const double b0 = (s == 0) ? 1. : 0., b2 = cx.beta2, g2 = cx.gamma2, a2 = cx.alpha2;
+    double *vt = cx.mp_vt + (size_t)s * cx.ks2h * 128;
+    double *uf = cx.mp_uf + (size_t)s * cx.rtph * 64;
+    for (int e = threadIdx.x; e < cx.ks2h * 128; e += blockDim.x) {
+        const int e2 = e & 1, lane = (e >> 1) & 63, m = e >> 7;
+        const int row = lane & 15, col = 8 * m + 2 * (lane >> 4) + e2;
+        double v = 0.;
+        if (row < 4 && col < 3 * N) {
+            const int ci = col / N, j = col % N + 1;
+            const double hw = 0.5 * cx.ga[j - 1];
+            const double f = (ci == 0) ? P[j] : (ci == 1 ? R[j] : T[j]);
+            const double c0[3] = {b2, g2, -g2}, c1[3] = {g2, a2, -a2}, c2[3] = {-g2, -a2, a2};
+            if (row == 0) v = hw * c0[ci] * f;
+            else if (row == 1) v = hw * c1[ci] * f;
+            else if (row == 2) v = hw * c2[ci] * f;
+            else v = (ci == 0) ? hw * b0 : 0.;
+        }
+        vt[e] = v;
+    }
+    for (int e = threadIdx.x; e < cx.rtph * 64; e += blockDim.x) {
+        const int lane = e & 63, rt = e >> 6;
+        const int row = rt * 16 + (lane & 15), k4 = lane >> 4;
+        double v = 0.;
+        if (row < 3 * N) {
+            const int co = row / N, k = row % N + 1;
+            if (co == 0) v = (k4 == 0) ? P[k] : (k4 == 3 ? ((s == 0) ? 1. : 0.) : 0.);
+            else if (co == 1) v = (k4 == 1) ? R[k] : 0.;
+            else v = (k4 == 2) ? T[k] : 0.;
+        }
+        uf[e] = v;
+    }
 }
 
 // Order-1 source vectors, one per state row r = (c, +-k):
@@ -241,6 +291,7 @@ void launch_noyaux(const SosDev &cx, hipStream_t st)
     const size_t per = (size_t)2 * cx.rtph * cx.ks2h * 128;
     dim3 g((unsigned)((per + 255) / 256), S);
     k_pack<<<g, 256, 0, st>>>(cx);
+    k_pack_ray<<<(cx.smax < 2 ? cx.smax + 1 : 3), 256, 0, st>>>(cx);
     k_sv<<<S, sos_round_up(cx.kp, 64), 0, st>>>(cx);
 }
 

@@ -40,7 +40,8 @@ struct SosDev {                 // per-wavelength device context, passed by valu
     const double *fres;         // [3][N] F11,F12,F33 at mu_k (SOS_OS.F:1753-1780)
     double *prt;                // [smax+1][3][os_nb+1][W]  P,R,T generalised spherical functions
     double *mp_aer;             // [smax+1][rtp*ks2*128]
-    double *mp_ray;             // [3][rtp*ks2*128]
+    double *mp_vt;              // [3][ks2h*128]  molecular operator, projection factor V^T (one 16-row tile, rows 0..3 used)
+    double *mp_uf;              // [3][rtph*64]   molecular operator, expansion factor U (K = 4)
     double *sv;                 // [smax+1][4][kp]: order-1 vectors aer, ray, fresnel-aer, fresnel-ray
     const float *rsurf;         // [smax+1][9][N][N] or null
 };

@@ -89,31 +89,44 @@ __device__ __forceinline__ double queue_term(double d, double g)
 }
 
 // Source contraction in the parity-decomposed form (sos_common.h): for both half systems
-//   acc[sys] += sum over passes of M^sys_pass * (scale_pass o X^sys),  X^A = X+ + g X-,  X^B = X+ - g X-
-// Pass 0 = aerosol operator with XDEL, pass 1 = molecular operator with YDEL (s <= 2 only).
+//   acc[sys] = XDEL o (M^sys X^sys),  X^A = X+ + g X-,  X^B = X+ - g X-        (aerosol operator, dense)
+// plus, for s <= 2, the molecular operator in its exact rank-4 form on the one half system it acts on:
+//   acc[sr] += U (YDEL o (V^T X^sr))                                             (noyaux.hip k_pack_ray)
 // LDS field rows: [0,KH) = X(+mu) in half-system order kk = c*N + (k-1), [KH,2KH) = X(-mu).
 // Each wave owns RTWH row tiles of BOTH systems (so S(+mu) = E^A + E^B and S(-mu) = g (E^A - E^B) are
-// formed in registers) x CT column tiles; one copy of the MFMA loop.
+// formed in registers) x CT column tiles.  FP64 VALU work in the loop is kept minimal (it competes with the
+// MFMAs for the FP64 datapath): g is applied as a sign-bit flip, XDEL/YDEL scale accumulators, not fragments.
+template <int CT>
+__device__ __forceinline__ void b_fragments(v2d (&ba)[CT], v2d (&bb)[CT], const double *const (&bp)[CT], int KH, int m,
+                                            int n2, int lane)
+{
+    const int kk0 = 8 * m + 2 * (lane >> 4);           // the two K indices of this lane: kk0, kk0+1
+    const unsigned long long f0 = (kk0 < n2) ? 0ull : 0x8000000000000000ull;      // g = -1 on the U rows
+    const unsigned long long f1 = (kk0 + 1 < n2) ? 0ull : 0x8000000000000000ull;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const v2d xp = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
+        const v2d xm = *reinterpret_cast<const v2d *>(bp[ct] + KH + 8 * m);
+        const double m0 = __longlong_as_double(__double_as_longlong(xm.x) ^ f0);
+        const double m1 = __longlong_as_double(__double_as_longlong(xm.y) ^ f1);
+        ba[ct].x = xp.x + m0; ba[ct].y = xp.y + m1;
+        bb[ct].x = xp.x - m0; bb[ct].y = xp.y - m1;
+    }
+}
+
 template <int RTWH, int CT>
-__device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp0,
-                                            const double *__restrict__ mp1, int pass_lo, int pass_hi, int ks2h, int rtph,
-                                            int n2, const double *fld, int CS, int KH, const double *scale0,
-                                            const double *scale1, int lane, int wv)
+__device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
+                                            const double *__restrict__ vt, const double *__restrict__ uf, int ray_sys,
+                                            int ks2h, int rtph, int n2, const double *fld, int CS, int KH,
+                                            const double *xdel, const double *ydel, int lane, int wv)
 {
     const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
     const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
     const double *bp[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) bp[ct] = fld + (size_t)(ct * 16 + (lane & 15)) * CS + 2 * (lane >> 4);
-#pragma unroll 1
-    for (int pass = pass_lo; pass < pass_hi; pass++) {
-        const v2d *ap = reinterpret_cast<const v2d *>(pass ? mp1 : mp0) + ((size_t)(wv * RTWH) * ks2h) * 64 + lane;
-        // pass 0 (aerosol): the column scale XDEL is applied to the accumulators once, after the loop;
-        // pass 1 (molecular, s <= 2, accumulating on top): the B fragments are scaled by YDEL on the fly.
-        const bool scale_b = pass != 0;
-        double sc[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) sc[ct] = (pass ? scale1 : scale0)[ct * 16 + (lane & 15)];
+    if (do_aer) {
+        const v2d *ap = reinterpret_cast<const v2d *>(mp) + ((size_t)(wv * RTWH) * ks2h) * 64 + lane;
         v2d a_cur[2][RTWH], a_nxt[2][RTWH];
 #pragma unroll
         for (int sy = 0; sy < 2; sy++)
@@ -127,22 +140,8 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
                     for (int rt = 0; rt < RTWH; rt++) a_nxt[sy][rt] = ap[sy * sys_stride + rt * rts + (size_t)(m + 1) * 64];
             }
-            // g = +1 for I,Q rows (kk < 2N), -1 for U rows: applied as a sign-bit flip (integer op, keeps the FP64
-            // datapath for the MFMAs); the two K indices of this lane are 8m+2q and 8m+2q+1
-            const int kk0 = 8 * m + 2 * (lane >> 4);
-            const unsigned long long f0 = (kk0 < n2) ? 0ull : 0x8000000000000000ull;
-            const unsigned long long f1 = (kk0 + 1 < n2) ? 0ull : 0x8000000000000000ull;
             v2d ba[CT], bb[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++) {
-                const v2d xp = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
-                const v2d xm = *reinterpret_cast<const v2d *>(bp[ct] + KH + 8 * m);
-                const double m0 = __longlong_as_double(__double_as_longlong(xm.x) ^ f0);
-                const double m1 = __longlong_as_double(__double_as_longlong(xm.y) ^ f1);
-                ba[ct].x = xp.x + m0; ba[ct].y = xp.y + m1;
-                bb[ct].x = xp.x - m0; bb[ct].y = xp.y - m1;
-                if (scale_b) { ba[ct].x *= sc[ct]; ba[ct].y *= sc[ct]; bb[ct].x *= sc[ct]; bb[ct].y *= sc[ct]; }
-            }
+            b_fragments<CT>(ba, bb, bp, KH, m, n2, lane);
 #pragma unroll
             for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
@@ -162,13 +161,46 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
                 for (int rt = 0; rt < RTWH; rt++) a_cur[sy][rt] = a_nxt[sy][rt];
         }
-        if (!scale_b) {     // XDEL of the output level: every accumulator register of a lane belongs to one column
+        // XDEL of the output level: every accumulator register of a lane belongs to one column
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const double sc = xdel[ct * 16 + (lane & 15)];
 #pragma unroll
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                for (int rt = 0; rt < RTWH; rt++)
+                for (int rt = 0; rt < RTWH; rt++) acc[sy][rt][ct] *= sc;
+        }
+    }
+    if (ray_sys >= 0) {
+        // projections pr = V^T X^sr: one 16-row tile (rows 0..3 used) per column tile, every wave computes them itself
+        // (64 MFMAs instead of the 256 of a dense pass, and no cross-wave exchange)
+        const v2d *vp = reinterpret_cast<const v2d *>(vt) + lane;
+        v4d pr[CT];
 #pragma unroll
-                    for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] *= sc[ct];
+        for (int ct = 0; ct < CT; ct++) pr[ct] = (v4d){0., 0., 0., 0.};
+#pragma unroll 1
+        for (int m = 0; m < ks2h; m++) {
+            const v2d a = vp[(size_t)m * 64];
+            v2d ba[CT], bb[CT];
+            b_fragments<CT>(ba, bb, bp, KH, m, n2, lane);
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const v2d b = ray_sys ? bb[ct] : ba[ct];
+                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, pr[ct], 0, 0, 0);
+                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, pr[ct], 0, 0, 0);
+            }
+        }
+        // register 0 of the result holds row (lane>>4) in 0..3, column lane&15: exactly the B-operand layout of one
+        // K = 4 step, so the expansion U * (YDEL o pr) needs no data movement
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const double q = pr[ct][0] * ydel[ct * 16 + (lane & 15)];
+#pragma unroll
+            for (int rt = 0; rt < RTWH; rt++) {
+                const double u = uf[(size_t)(wv * RTWH + rt) * 64 + lane];
+                if (ray_sys) acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[1][rt][ct], 0, 0, 0);
+                else acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[0][rt][ct], 0, 0, 0);
+            }
         }
     }
 }
@@ -447,9 +479,10 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                         }
                         __syncthreads();
                     }
-                    gemm_source<RTWH, CT>(acc, cx.mp_aer + (size_t)s * mper, cx.mp_ray + (size_t)(s <= 2 ? s : 0) * mper,
-                                          has_aer ? 0 : 1, s <= 2 ? 2 : 1, cx.ks2h, cx.rtph, 2 * N, cbuf, CS, KH,
-                                          xdel + l0, ydel + l0, lane, wv);
+                    gemm_source<RTWH, CT>(acc, cx.mp_aer + (size_t)s * mper, has_aer != 0,
+                                          cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128,
+                                          cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64, s <= 2 ? (s & 1) : -1,
+                                          cx.ks2h, cx.rtph, 2 * N, cbuf, CS, KH, xdel + l0, ydel + l0, lane, wv);
                     __syncthreads();
                     PH(2);
 #pragma unroll
