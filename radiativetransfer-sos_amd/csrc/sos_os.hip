@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
 #ifdef SOS_SCAN_UNROLL_FORCE
     constexpr int SU = SOS_SCAN_UNROLL_FORCE;
 #else
-    constexpr int SU = (ZO || BIG) ? 1 : 4;      // formal-solution unroll: bounded by the register budget of each variant
+    constexpr int SU = (ZO || BIG) ? 4 : 8;      // formal-solution block (levels held in registers at once)
 #endif
     const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
     const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
@@ -337,28 +337,32 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             double sn = fld[(size_t)i0 * FS + rl];      // source at the level the ray comes from
             fld[(size_t)i0 * FS + rl] = z;
             if (ZO) { if (i0 == jlo) xlo = z; if (i0 == jhi) xhi = z; }
-            // software pipeline: coefficients are fetched two levels ahead (L2 latency), the source one level ahead,
-            // all BEFORE the in-place store of the current level (the compiler cannot hoist them across it itself)
+            // blocks of SU levels: all operands of a block (source from LDS/scratch, attenuation, p, w tables) are
+            // loaded up front into registers -- one memory latency per block instead of one per level -- then the
+            // SU dependent FMAs run back to back and the block is stored.  (The loads must be explicit: the compiler
+            // cannot move them across the in-place stores of the previous levels.)
             const double *prow = pqt + jj, *wrow = wt + jj;
-            const int lstep = di;                                   // layer index moves with the ray
-            int i = i0 + di;
-            int li = up ? i0 - 1 : i0;                              // layer between levels li and li+1
-            int li2 = (nt > 1) ? li + lstep : li;
-            double a0 = arow[li * N], p0 = prow[li * N], w0 = wrow[li * N];
-            double a1c = arow[li2 * N], p1 = prow[li2 * N], w1 = wrow[li2 * N];
-            double si = fld[(size_t)i * FS + rl];
-#pragma unroll SU
-            for (int k = 0; k < nt; ++k) {
-                const int in = (k + 1 < nt) ? i + di : i;           // next level (clamped on the last trips)
-                const int li3 = (k + 2 < nt) ? li2 + lstep : li2;
-                const double a2 = arow[li3 * N], p2 = prow[li3 * N], w2 = wrow[li3 * N];
-                const double si_n = fld[(size_t)in * FS + rl];
-                z = z * a0 + (p0 * si + w0 * sn);
-                fld[(size_t)i * FS + rl] = z;
-                if (ZO) { if (i == jlo) xlo = z; if (i == jhi) xhi = z; }
-                sn = si; si = si_n;
-                a0 = a1c; p0 = p1; w0 = w1; a1c = a2; p1 = p2; w1 = w2;
-                i = in; li2 = li3;
+            const int lay0 = up ? i0 - 1 : i0;                      // first layer crossed; the layer index moves with di
+#pragma unroll 1
+            for (int k0 = 0; k0 < nt; k0 += SU) {
+                double sv[SU], av[SU], pv[SU], wv2[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int kc = min(k0 + u, nt - 1);
+                    const int lev = i0 + di * (kc + 1), lay = lay0 + di * kc;
+                    sv[u] = fld[(size_t)lev * FS + rl];
+                    av[u] = arow[lay * N]; pv[u] = prow[lay * N]; wv2[u] = wrow[lay * N];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    if (k0 + u < nt) {
+                        const int lev = i0 + di * (k0 + u + 1);
+                        z = z * av[u] + (pv[u] * sv[u] + wv2[u] * sn);
+                        fld[(size_t)lev * FS + rl] = z;
+                        sn = sv[u];
+                        if (ZO) { if (lev == jlo) xlo = z; if (lev == jhi) xhi = z; }
+                    }
+                }
             }
             xb = z;
             if (!up) gnd[c * N + jj] = z;
