@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--g", type=float, default=0.75)
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-sort", action="store_true", help="keep the bins in generation order (default: cost-sorted upload)")
     args = ap.parse_args()
 
     import torch
@@ -100,8 +101,11 @@ def main():
     lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
     al, be, ga, ze = wl["coefs"]
     cx = pkg.SosContext(wl["mu"], wl["w"], wl["n0"], al, be, ga, ze, iborm_max=wl["iborm"], ro=0.1, device=dev)
-    bins = cx.upload_bins(wl["h"][lo:hi], wl["xdel"][lo:hi], wl["ydel"][lo:hi])
-    aik = torch.from_numpy(wl["aik"][lo:hi].copy()).to(cx.device)
+    bins = cx.upload_bins(wl["h"][lo:hi], wl["xdel"][lo:hi], wl["ydel"][lo:hi], order=None if args.no_sort else "cost")
+    aik_h = wl["aik"][lo:hi].copy()
+    if bins["perm"] is not None:
+        aik_h = aik_h[bins["perm"]]
+    aik = torch.from_numpy(aik_h).to(cx.device)
     out = cx.alloc_outputs(hi - lo)
     torch.cuda.synchronize()
 

@@ -233,10 +233,8 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     if (rc) return rc;
     int per_launch = nb;
     const int lpb = sos_round_up(lp, 32);
-    const int lpt = big ? lpb : 16 * ct;                                  // level capacity of the coefficient tables
-    const size_t tab_bin = (size_t)2 * lpt * cx->d.n;                     // p and w tables
-    const size_t per_bin = (big ? sos_os_scratch_doubles(cx->d.n, lpb) : 0) + tab_bin;
-    {
+    const size_t per_bin = big ? sos_os_scratch_doubles(cx->d.n, lpb) : 0;
+    if (big) {
         const size_t cap = ((size_t)8 << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
         const size_t need = per_bin * per_launch;
@@ -258,8 +256,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         bn.prof = d_prof + (size_t)b0 * 3 * lp; bn.zz = d_zz ? d_zz + b0 : nullptr;
         bn.rec = d_rec + (size_t)b0 * S1 * 3 * W; bn.flux = d_flux + (size_t)2 * b0;
         bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
-        bn.scratch = big ? cx->scratch + tab_bin : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
-        bn.tabs = cx->scratch; bn.tab_stride = per_bin;
+        bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
         rc = launch_sos_os(cx->d, bn, nt_max, st);
         if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }

@@ -57,8 +57,6 @@ struct SosBins {
     double *scratch;
     size_t scr_stride;
     int lpb;
-    double *tabs;                // per-bin formal-solution coefficient tables [2][lpt][N] (p, w)
-    size_t tab_stride;
     unsigned long long *phase;   // diagnostic builds only (SOS_PROFILE_PHASES): [nb][8] cycle sums per phase
 };
 

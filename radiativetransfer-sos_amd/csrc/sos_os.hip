@@ -20,6 +20,7 @@
 //    per-thread register state.
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
+#include <cstdlib>
 #include "sos_common.h"
 #include "kernels.h"
 
@@ -88,29 +89,34 @@ __device__ __forceinline__ double queue_term(double d, double g)
     return (d == 0.) ? 0. : (g * d) / (d - g);
 }
 
+// Instruction budget.  Two workgroups share a CU, one wave of each per SIMD.  While one wave streams
+// v_mfma_f64 (64 cycles each, back to back) its partner gets only the left-over vector-issue slots, and every
+// vector instruction of either wave delays the next MFMA.  Measured (phase stamps, profiles/): every non-MFMA VALU
+// instruction costs ~12-15 cycles in this regime whatever its kind, so the non-contraction phases are written for
+// the LOWEST VALU INSTRUCTION COUNT (running pointers, immediate offsets, no predicates, no divisions), not for
+// latency.
+//
+// Field storage convention: rows [0,KH) hold X(+mu), rows [KH,2KH) hold X(-mu) in half-system order
+// kk = c*N + (k-1), and the U component of the down-going half is stored NEGATED (V- = -U(-mu)).  With that the
+// parity combinations need no per-row sign:  X^A = X+ + X-,  X^B = X+ - X-,  S+ = E^A + E^B,  S- = E^A - E^B
+// (for U: X^A_U = U+ - U-, stored S-_U = -(E^B - E^A)); the formal solution is linear with a zero boundary for
+// down-going rows, so it maps a negated source to a negated field.  The sign is restored where U(-mu) leaves the
+// field: ground values (gnd) and output records.
+//
 // Source contraction in the parity-decomposed form (sos_common.h): for both half systems
-//   acc[sys] = XDEL o (M^sys X^sys),  X^A = X+ + g X-,  X^B = X+ - g X-        (aerosol operator, dense)
+//   acc[sys] = XDEL o (M^sys X^sys)                                              (aerosol operator, dense)
 // plus, for s <= 2, the molecular operator in its exact rank-4 form on the one half system it acts on:
 //   acc[sr] += U (YDEL o (V^T X^sr))                                             (noyaux.hip k_pack_ray)
-// LDS field rows: [0,KH) = X(+mu) in half-system order kk = c*N + (k-1), [KH,2KH) = X(-mu).
-// Each wave owns RTWH row tiles of BOTH systems (so S(+mu) = E^A + E^B and S(-mu) = g (E^A - E^B) are
-// formed in registers) x CT column tiles.  FP64 VALU work in the loop is kept minimal (it competes with the
-// MFMAs for the FP64 datapath): g is applied as a sign-bit flip, XDEL/YDEL scale accumulators, not fragments.
+// Each wave owns RTWH row tiles of BOTH systems x CT column tiles.
 template <int CT>
-__device__ __forceinline__ void b_fragments(v2d (&ba)[CT], v2d (&bb)[CT], const double *const (&bp)[CT], int KH, int m,
-                                            int n2, int lane)
+__device__ __forceinline__ void b_fragments(v2d (&ba)[CT], v2d (&bb)[CT], const double *const (&bp)[CT], int KH, int m)
 {
-    const int kk0 = 8 * m + 2 * (lane >> 4);           // the two K indices of this lane: kk0, kk0+1
-    const unsigned long long f0 = (kk0 < n2) ? 0ull : 0x8000000000000000ull;      // g = -1 on the U rows
-    const unsigned long long f1 = (kk0 + 1 < n2) ? 0ull : 0x8000000000000000ull;
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
         const v2d xp = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
         const v2d xm = *reinterpret_cast<const v2d *>(bp[ct] + KH + 8 * m);
-        const double m0 = __longlong_as_double(__double_as_longlong(xm.x) ^ f0);
-        const double m1 = __longlong_as_double(__double_as_longlong(xm.y) ^ f1);
-        ba[ct].x = xp.x + m0; ba[ct].y = xp.y + m1;
-        bb[ct].x = xp.x - m0; bb[ct].y = xp.y - m1;
+        ba[ct] = xp + xm;
+        bb[ct] = xp - xm;
     }
 }
 
@@ -127,40 +133,43 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
     for (int ct = 0; ct < CT; ct++) bp[ct] = fld + (size_t)(ct * 16 + (lane & 15)) * CS + 2 * (lane >> 4);
     if (do_aer) {
         const v2d *ap = reinterpret_cast<const v2d *>(mp) + ((size_t)(wv * RTWH) * ks2h) * 64 + lane;
-        v2d a_cur[2][RTWH], a_nxt[2][RTWH];
-#pragma unroll
-        for (int sy = 0; sy < 2; sy++)
-#pragma unroll
-            for (int rt = 0; rt < RTWH; rt++) { a_cur[sy][rt] = ap[sy * sys_stride + rt * rts]; a_nxt[sy][rt] = a_cur[sy][rt]; }
-#pragma unroll 1
-        for (int m = 0; m < ks2h; m++) {
-            if (m + 1 < ks2h) {
-#pragma unroll
-                for (int sy = 0; sy < 2; sy++)
-#pragma unroll
-                    for (int rt = 0; rt < RTWH; rt++) a_nxt[sy][rt] = ap[sy * sys_stride + rt * rts + (size_t)(m + 1) * 64];
-            }
-            v2d ba[CT], bb[CT];
-            b_fragments<CT>(ba, bb, bp, KH, m, n2, lane);
-#pragma unroll
-            for (int rt = 0; rt < RTWH; rt++)
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
-                }
-#pragma unroll
-            for (int rt = 0; rt < RTWH; rt++)
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
-                }
+        // two register sets of A fragments used alternately (k-pair m from one set while m+1 loads into the other):
+        // no register-to-register copies in the loop
+        v2d a0[2][RTWH], a1[2][RTWH];
+        auto load_a = [&](v2d (&a)[2][RTWH], int m) {
 #pragma unroll
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                for (int rt = 0; rt < RTWH; rt++) a_cur[sy][rt] = a_nxt[sy][rt];
+                for (int rt = 0; rt < RTWH; rt++) a[sy][rt] = ap[sy * sys_stride + rt * rts + (size_t)m * 64];
+        };
+        auto mma = [&](const v2d (&a)[2][RTWH], int m) {
+            v2d ba[CT], bb[CT];
+            b_fragments<CT>(ba, bb, bp, KH, m);
+#pragma unroll
+            for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
+                }
+#pragma unroll
+            for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
+                }
+        };
+        load_a(a0, 0);
+        int m = 0;
+#pragma unroll 1
+        for (; m + 1 < ks2h; m += 2) {
+            load_a(a1, m + 1);
+            mma(a0, m);
+            if (m + 2 < ks2h) load_a(a0, m + 2);
+            mma(a1, m + 1);
         }
+        if (m < ks2h) mma(a0, m);
         // XDEL of the output level: every accumulator register of a lane belongs to one column
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
@@ -182,7 +191,7 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
         for (int m = 0; m < ks2h; m++) {
             const v2d a = vp[(size_t)m * 64];
             v2d ba[CT], bb[CT];
-            b_fragments<CT>(ba, bb, bp, KH, m, n2, lane);
+            b_fragments<CT>(ba, bb, bp, KH, m);
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const v2d b = ray_sys ? bb[ct] : ba[ct];
@@ -210,15 +219,19 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 //              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of
 //              16*CT levels staged through LDS, the formal solution streams the scratch with batched loads.
 // ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- tracks two extra levels per row.
+// Register bound: 256 architectural VGPRs for every variant (two workgroups per CU when the LDS allows it).  The
+// 512-register form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded
+// form with a few scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one of its instantiations
+// (<2,4,false,true> with a 4-level scan block) produced wrong down-going rows on gfx950, so it is not used.
 template <int RTWH, int CT, bool BIG, bool ZO>
-__global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
+__global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
     constexpr int COLS = 16 * CT;
 #ifdef SOS_SCAN_UNROLL_FORCE
     constexpr int SU = SOS_SCAN_UNROLL_FORCE;
 #else
-    constexpr int SU = (ZO || BIG) ? 4 : 8;      // formal-solution block (levels held in registers at once)
+    constexpr int SU = 4;                        // formal-solution unroll
 #endif
     const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
     const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
@@ -239,9 +252,6 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
     double *ch = ydel + LPB;
     double *fco = ch + LPB;
     double *hh = fco + LPB;
-    // formal-solution coefficients p, w per (layer, direction): per-bin table in HBM/L2 (no LDS left for them)
-    double *pqt = bn.tabs + (size_t)blockIdx.x * bn.tab_stride;
-    double *wt = pqt + (size_t)LPB * N;
 
 #ifdef SOS_STATIC_PRIO
     // Two workgroups share a CU (one wave of each per SIMD).  Give the one whose LDS allocation starts at 0 a
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
     if ((__builtin_amdgcn_s_getreg(0x3806) & 0xff) == 0) __builtin_amdgcn_s_setprio(SOS_STATIC_PRIO);
 #endif
     // thread -> state row: t < 3N up-going (+mu), 3N <= t < 6N down-going; kk = c*N + jj in both halves
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool active = t < R6;
     const bool up = t < 3 * N;
     const int kk = active ? (up ? t : t - 3 * N) : 0;
@@ -299,13 +309,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             if (i <= nt && xdel[i] != 0.) aer_l = 1;
         }
         const int has_aer = uniform_i32(__syncthreads_or(aer_l));
-        for (int i = t; i < nt * N; i += 256) {                                               // SOS_OS.F:2291,2335
-            const int li = i / N, j = i % N;
-            const double a_t = exp(-dtau[li] / cx.mu[j]);
-            const double omt = 1.0 - a_t;
-            const double w = (omt * cx.mu[j] - a_t * dtau[li]) * idtau[li];
-            att[i] = a_t; wt[i] = w; pqt[i] = omt - w;
-        }
+        for (int i = t; i < nt * N; i += 256) att[i] = exp(-dtau[i / N] / cx.mu[i % N]);      // SOS_OS.F:2291,2335
         // bin-constant exponentials of the ground boundary terms (SOS_OS.F:979,985,1068-1077)
         const double e_sun = uniform_f64(exp(-htot / cx.mus));
         double e_mu = 0., e_lo = 0., e_hi = 0.;
@@ -319,56 +323,49 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
         // per-thread formal solution of its row, in place over the source held in fld (SOS_INTEGR_EPOPT,
         // SOS_OS.F:2279-2354).  bcv = value at the ground for up-going rows.  With t = exp(-dtau/|mu|) and the
         // source linear in tau on the layer, both directions reduce to the same three-term recurrence
-        //     X_i = t X_n + p S_i + w S_n,   w = ((1-t)|mu| - t dtau)/dtau,  p = (1-t) - w
-        // (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), which is algebraically
-        // the reference update X t + (1-t)(a mu + b) -/+ a t dtau.  Up- and down-going rows share ONE instruction
-        // stream (per-lane level index), so wavefronts holding both kinds of rows do not run the loop twice, and
-        // only one FMA per level sits on the dependent chain.
+        //     X_i = t X_n + p S_i + w S_n,   w = (1-t) |mu|/dtau - t,  p = (1-t) - w
+        // (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), algebraically the
+        // reference update X t + (1-t)(a mu + b) -/+ a t dtau.  Up- and down-going rows share ONE instruction stream
+        // (per-lane start level and stride), all addresses are running pointers: ~11 vector instructions per level.
+        const double usign = (c == 2 && !up) ? -1. : 1.;     // U(-mu) is stored negated (see gemm_source)
         double xb, xlo = 0., xhi = 0.;
         auto scan_row = [&](double bcv) {
             if (!active) { xb = 0.; return; }
-#ifdef SOS_SCAN_PRIO
-            __builtin_amdgcn_s_setprio(SOS_SCAN_PRIO);
-#endif
-            const double *arow = att + jj;
             const int i0 = up ? nt : 0;                 // level the ray starts from
             const int di = up ? -1 : 1;
+            const int lay0 = up ? nt - 1 : 0;           // first layer crossed; the layer index moves with di
+            double *sp = fld + (size_t)i0 * FS + rl;
+            const ptrdiff_t sst = (ptrdiff_t)di * FS;
+            const double *ap = att + lay0 * N + jj;
+            const int ast = di * N;
+            const double *dp = dtau + lay0;             // idtau = dtau + LPB
             double z = up ? bcv : 0.;
-            double sn = fld[(size_t)i0 * FS + rl];      // source at the level the ray comes from
-            fld[(size_t)i0 * FS + rl] = z;
+            double sn = *sp;                            // source at the level the ray comes from
+            *sp = z;
             if (ZO) { if (i0 == jlo) xlo = z; if (i0 == jhi) xhi = z; }
-            // blocks of SU levels: all operands of a block (source from LDS/scratch, attenuation, p, w tables) are
-            // loaded up front into registers -- one memory latency per block instead of one per level -- then the
-            // SU dependent FMAs run back to back and the block is stored.  (The loads must be explicit: the compiler
-            // cannot move them across the in-place stores of the previous levels.)
-            const double *prow = pqt + jj, *wrow = wt + jj;
-            const int lay0 = up ? i0 - 1 : i0;                      // first layer crossed; the layer index moves with di
+            int lev = i0;
+            auto level = [&]() {
+                sp += sst;
+                const double a = *ap, si = *sp, r = mu * dp[LPB];
+                const double omt = 1.0 - a;
+                const double w = omt * r - a;
+                const double pq = omt - w;
+                z = z * a + (pq * si + w * sn);
+                *sp = z;
+                sn = si;
+                ap += ast; dp += di;
+                if (ZO) { lev += di; if (lev == jlo) xlo = z; if (lev == jhi) xhi = z; }
+            };
+            int k = 0;
 #pragma unroll 1
-            for (int k0 = 0; k0 < nt; k0 += SU) {
-                double sv[SU], av[SU], pv[SU], wv2[SU];
+            for (; k + SU <= nt; k += SU) {             // exact trip counts: blocks of SU levels, then the tail
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int kc = min(k0 + u, nt - 1);
-                    const int lev = i0 + di * (kc + 1), lay = lay0 + di * kc;
-                    sv[u] = fld[(size_t)lev * FS + rl];
-                    av[u] = arow[lay * N]; pv[u] = prow[lay * N]; wv2[u] = wrow[lay * N];
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    if (k0 + u < nt) {
-                        const int lev = i0 + di * (k0 + u + 1);
-                        z = z * av[u] + (pv[u] * sv[u] + wv2[u] * sn);
-                        fld[(size_t)lev * FS + rl] = z;
-                        sn = sv[u];
-                        if (ZO) { if (lev == jlo) xlo = z; if (lev == jhi) xhi = z; }
-                    }
-                }
+                for (int u = 0; u < SU; ++u) level();
             }
+#pragma unroll 1
+            for (; k < nt; ++k) level();
             xb = z;
-            if (!up) gnd[c * N + jj] = z;
-#ifdef SOS_SCAN_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            if (!up) gnd[c * N + jj] = z * usign;
         };
 
         double i4 = 0., i5 = 0.;
@@ -424,7 +421,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                     double v = ch[i] * (sva * xdel[i] + svr * ydel[i]);              // SOS_OS.F:2557-2559
                     if (cx.ifresnel == 1 && (up ? (i < nt) : (i >= 1)))
                         v = v + fco[i] * (sfa * xdel[i] + sfr * ydel[i]);            // SOS_OS.F:3280-3289
-                    fld[(size_t)i * FS + rl] = v;
+                    fld[(size_t)i * FS + rl] = v * usign;
                 }
             }
             double bc = 0., dirterm = 0.;
@@ -489,21 +486,28 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
                                           cx.ks2h, cx.rtph, 2 * N, cbuf, CS, KH, xdel + l0, ydel + l0, lane, wv);
                     __syncthreads();
                     PH(2);
-#pragma unroll
-                    for (int rt = 0; rt < RTWH; rt++)
+                    // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
+                    // accumulators are exact zeros (zero operator rows, zero field columns) and are stored as such.
+                    {
+                        double *wb = cbuf + (size_t)(lane & 15) * CS + (wv * RTWH) * 16 + (lane >> 4);
 #pragma unroll
                         for (int ct = 0; ct < CT; ct++) {
-                            const int col = ct * 16 + (lane & 15);
+                            double *wp = wb + (size_t)ct * 16 * CS, *wm = wp + KH;
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const int row = (wv * RTWH + rt) * 16 + (lane >> 4) + 4 * e;   // half-system index kk
-                                if (row < 3 * N && l0 + col <= nt) {
-                                    const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
-                                    cbuf[col * CS + row] = ea + eb;                               // S(+mu)
-                                    cbuf[col * CS + KH + row] = (row < 2 * N) ? (ea - eb) : (eb - ea);   // S(-mu) = g (E^A - E^B)
-                                }
+                            for (int rt = 0; rt < RTWH; rt++) {
+                                // rows of this tile inside the half system (KH is a multiple of 8, register e holds
+                                // rows 4e..4e+3 of the tile): a wave-uniform count, no lane predicate
+                                const int ne = (KH - (wv * RTWH + rt) * 16) >> 2;
+#pragma unroll
+                                for (int e = 0; e < 4; e++)
+                                    if (e < ne) {
+                                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                                        wp[rt * 16 + 4 * e] = ea + eb;
+                                        wm[rt * 16 + 4 * e] = ea - eb;
+                                    }
                             }
                         }
+                    }
                     __syncthreads();
                     if (BIG) {                                 // source chunk: LDS -> scratch
                         const int per_lev = KH;
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256, (RTWH * CT <= 4) ? 2 : 1) void k_sos_os(const 
             i5 = i5 + coef * i3 * sign;
             if (active) {                                                            // SOS_OS.F:1484-1534,1572
                 const double outv = (ZO && jout) ? ((1 - zz) * i3lo + zz * i3hi) : i3out0;
-                recb[(size_t)s * 3 * W + recoff] = outv;
+                recb[(size_t)s * 3 * W + recoff] = outv * usign;
                 if (up && jj == 0) recb[(size_t)s * 3 * W + c * W + N] = 0.;
             }
             if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
@@ -616,7 +620,7 @@ int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes, int 
     const int r = (rth + 3) / 4;
     int c = 0, b = 0;
     if (nt_max + 1 <= 32 && lds_bytes_for(n, 2, false) <= 160 * 1024) c = 2;
-    else if (nt_max + 1 <= 64 && r <= 3 && lds_bytes_for(n, 4, false) <= 160 * 1024) c = 4;
+    else if (nt_max + 1 <= 64 && r <= 3 && lds_bytes_for(n, 4, false) <= 160 * 1024 && !getenv("SOSGPU_DEBUG_FORCE_BIG")) c = 4;
     else { c = 2; b = 1; }
     const size_t lb = lds_bytes_for(n, c, b);
     if (lb > 160 * 1024) return SOSGPU_E_UNSUPPORTED;

@@ -92,14 +92,26 @@ class SosContext:
             d[k] = out[6 * w * w + i * w:6 * w * w + (i + 1) * w]
         return d
 
-    def upload_bins(self, h, xdel, ydel, nt=None, iborm=None, zout=-1.0, zprof=None):
+    def upload_bins(self, h, xdel, ydel, nt=None, iborm=None, zout=-1.0, zprof=None, order=None):
         """Pack per-bin profiles (after the SOS.F rescale) into the device layout of sosgpu_os_solve.
-        h/xdel/ydel: [nb][L] arrays (ragged bins: pass nt[nb] and pad)."""
+        h/xdel/ydel: [nb][L] arrays (ragged bins: pass nt[nb] and pad).
+        order="cost": bins are permuted by decreasing total optical depth before upload (the returned dict holds
+        `perm`, with result[i] belonging to input bin perm[i]).  Bins of similar cost then run side by side, drift
+        less across Fourier orders and keep re-reading the same source operators from L2 (scheduling only: every
+        bin's result is unchanged)."""
         h = np.atleast_2d(np.asarray(h, dtype=np.float64))
         xdel = np.atleast_2d(np.asarray(xdel, dtype=np.float64))
         ydel = np.atleast_2d(np.asarray(ydel, dtype=np.float64))
         nb, lmax = h.shape
         nt = np.full(nb, lmax - 1, dtype=np.int32) if nt is None else np.asarray(nt, dtype=np.int32)
+        perm = None
+        if order == "cost":
+            perm = np.argsort(-h[np.arange(nb), nt], kind="stable")
+            h, xdel, ydel, nt = h[perm], xdel[perm], ydel[perm], nt[perm]
+            if iborm is not None and np.ndim(iborm):
+                iborm = np.asarray(iborm)[perm]
+            if zprof is not None:
+                zprof = np.atleast_2d(np.asarray(zprof, dtype=np.float64))[perm]
         lp = int(-(-lmax // 16) * 16)
         prof = np.zeros((nb, 3, lp))
         prof[:, 0, :lmax], prof[:, 1, :lmax], prof[:, 2, :lmax] = h, xdel, ydel
@@ -120,7 +132,7 @@ class SosContext:
                 jout[b] = j
                 zz[b] = (zout - zprof[b, j - 1]) / (zprof[b, j] - zprof[b, j - 1])
         d = self.device
-        return dict(nb=nb, lp=lp, nt=_dev_i32(nt, d), iborm=_dev_i32(iborm, d), prof=_dev_f64(prof, d),
+        return dict(nb=nb, lp=lp, perm=perm, nt=_dev_i32(nt, d), iborm=_dev_i32(iborm, d), prof=_dev_f64(prof, d),
                     jout=None if jout is None else _dev_i32(jout, d), zz=None if zz is None else _dev_f64(zz, d))
 
     def alloc_outputs(self, nb):

@@ -68,6 +68,12 @@ def make_case(name):
     elif name == "aer_n9_nt600":          # CTE_OS_NT = 600 (SOS.h:202)
         ng, nt, os_nb, g, kabs = 8, 600, 16, 0.5, [1.0]
         kw = dict(ro=0.1)
+    elif name.startswith("x_"):           # ad-hoc debugging case: x_<ng>_<nt>_<os_nb>_<g>_<zout or -1>
+        f = name.split("_")
+        ng, nt, os_nb, g, kabs = int(f[1]), int(f[2]), int(f[3]), float(f[4]), [0.0]
+        kw = dict(ro=0.1)
+        if float(f[5]) >= 0:
+            kw["zout"] = float(f[5])
     else:
         raise KeyError(name)
     mu, w, n0 = S.gauss_angles(ng, 35.0)
