@@ -101,7 +101,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     const int rt = (6 * N + 15) / 16;
     d.rtp = 4 * ((rt + 3) / 4);
     d.kh = sos_round_up(3 * N, 8); d.ks2h = d.kh / 8;
-    d.rtph = 4 * (((d.kh / 16 + ((d.kh % 16) ? 1 : 0)) + 3) / 4);
+    d.rtph = (d.kh + 15) / 16;
     d.os_nb = B; d.smax = iborm_max;
     d.n0 = wv->n0; d.imat_surf = wv->imat_surf == 1; d.ifresnel = wv->ifresnel == 1 ? 1 : 0;
     d.igmax = wv->igmax; d.ipolar = wv->ipolar ? 1 : 0;
@@ -226,10 +226,10 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     hipStream_t st = (hipStream_t)stream;
     // variant: field in LDS, or (NT too large) field in a per-bin HBM scratch, launched in sub-batches so that
     // the scratch stays below ~8 GiB
-    int rtw, ct, big;
+    int nw, rtw, ct, big;
     size_t lds;
     const int nt_max = lp - 1;          // lp - 1 bounds every NT of the batch (the host pads the level axis to lp)
-    int rc = sos_os_variant(cx->d.n, nt_max, &rtw, &ct, &lds, &big);
+    int rc = sos_os_variant(cx->d.n, nt_max, &nw, &rtw, &ct, &lds, &big);
     if (rc) return rc;
     int per_launch = nb;
     const int lpb = sos_round_up(lp, 32);

@@ -7,8 +7,8 @@ void launch_noyaux_fetch(const SosDev &cx, int s, double *d_out, hipStream_t st)
 
 // Fused successive-orders solver.  Returns 0, or SOSGPU_E_UNSUPPORTED when (N, max NT) has no variant.
 int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st);
-// LDS bytes / row-tiles-per-wave the solver would use (for planning and tests); <0 if unsupported.
-int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes, int *big);
+// waves / row-tiles-per-wave / column tiles / LDS bytes the solver would use (for planning and tests); <0 if unsupported.
+int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_bytes, int *big);
 // doubles of per-bin scratch the field-in-HBM variant needs for lpb levels
 size_t sos_os_scratch_doubles(int n, int lpb);
 

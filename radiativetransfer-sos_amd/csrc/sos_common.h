@@ -27,7 +27,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 struct SosDev {                 // per-wavelength device context, passed by value to the kernels
     int n, w, r6;               // N, 2N+1, 6N
     int kp, ks2, rtp;           // order-1 vector stride (6N padded to 8); legacy full-operator sizes (unused by the solver)
-    int kh, ks2h, rtph;         // half system: 3N padded to 8, kh/8, padded row tiles per system (4*RTWH)
+    int kh, ks2h, rtph;         // half system: 3N padded to 8, kh/8, 16-row tiles per system ceil(kh/16)
     int os_nb, smax;            // OS_NB, iborm_max
     int n0, imat_surf, ifresnel, igmax, ipolar;
     double mus;                 // cos(solar zenith) = mu[n0-1]; the reference's TAB = -mus
@@ -53,7 +53,7 @@ struct SosBins {
     double *rec, *flux;
     int32_t *norders, *iglast;
     // field-in-HBM variant (NT too large for LDS): per-bin scratch of scr_stride doubles laid out
-    // [lpb][2*KH] field | [lpb][N] attenuations | [7][lpb] level vectors
+    // [lpb][FS] field | [lpb][NS] attenuations | [7][lpb] level vectors (FS, NS: strides of the variant, sos_os.hip)
     double *scratch;
     size_t scr_stride;
     int lpb;

@@ -5,29 +5,27 @@
 // with its leaves SOS_FSOURCE_ORDRE1 (:2431), SOS_FSOURCE_ORDREIG (:2663), SOS_INTEGR_EPOPT (:2222),
 // SOS_FSOURCE_DIFF_FRESNEL1 (:3106), the stop tests (:3377,:3497,:3585,:3709) and SOS_AJOUT_QUEUE (:3871).
 //
-// MI355X mapping (one 256-thread workgroup = one bin, all Fourier orders s and scattering orders ig):
-//  * the radiance field L(6N rows x NT+1 levels) of the current scattering order lives in LDS for the
-//    whole solve, laid out [level][row] (row contiguous) with a level stride of KP+2 doubles;
-//  * the order-ig source S = M_s (XDEL o L) [+ M_ray,s (YDEL o L) for s <= 2] is a dense
-//    [6N x 6N] x [6N x (NT+1)] FP64 contraction run on v_mfma_f64_16x16x4_f64: each of the 4 waves owns
-//    RTW row tiles x CT column tiles of accumulators (registers); the operator M_s streams from L2/MALL
-//    in pre-packed A-fragment order (1 KiB contiguous per wave load), the B fragments come from LDS and
-//    are scaled by XDEL/YDEL of their level in registers;
-//  * S overwrites L in LDS, then one thread per (Stokes, direction) row runs the layer-by-layer formal
-//    solution (SOS_INTEGR_EPOPT) in place, using attenuations exp(-dtau/mu) precomputed once per bin;
-//  * stop tests are three max-reductions per scattering order fused into one wavefront-shuffle +
-//    LDS reduction; the geometric-series tail, the Fourier accumulation and the Fourier stop are
-//    per-thread register state.
+// MI355X mapping (one workgroup of NW waves = one bin, all Fourier orders s and scattering orders ig):
+//  * the radiance field of the current scattering order, 2 x 3N rows x NT+1 levels, lives in LDS for the whole
+//    solve, laid out [level][row] with a COMPILE-TIME level stride FS = 2 KHM + 2 doubles (KHM = 16 NW RTWH rows
+//    per direction half, the capacity of the variant), rows [0,KHM) = X(+mu), [KHM,2KHM) = X(-mu);
+//  * the order-ig source is the parity-decomposed dense FP64 contraction (two 3N x 3N half systems, see
+//    sos_common.h) on v_mfma_f64_16x16x4_f64: wave w owns row tiles {w, w+NW} of BOTH systems x CT column tiles
+//    of accumulators; the operator streams from L2/MALL in pre-packed A-fragment order (1 KiB contiguous per wave
+//    load), the B fragments X+ +- X- are formed from LDS (one ds_read_b128 per lane per pair of k-steps);
+//  * the source overwrites the field in LDS, then one thread per (Stokes, direction) row runs the layer-by-layer
+//    formal solution (SOS_INTEGR_EPOPT) in place; waves [0,NW/2) hold the up-going rows, waves [NW/2,NW) the
+//    down-going rows, so the direction of the sweep is wave-uniform and every LDS address of a block of levels is
+//    a compile-time immediate offset from one base register;
+//  * stop tests are predicate bits OR-ed over the workgroup (no FP reductions, no divisions); the geometric-series
+//    tail, the Fourier accumulation and the Fourier stop are per-thread register state.
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
-#include <cstdlib>
+#include <type_traits>
 #include "sos_common.h"
 #include "kernels.h"
 
 #define SOSGPU_E_UNSUPPORTED -3
-#ifndef SOS_SCAN_UNROLL
-#define SOS_SCAN_UNROLL 4
-#endif
 #ifdef SOS_PROFILE_PHASES
 #define PH_T0() unsigned long long ph_t = __builtin_amdgcn_s_memtime()
 #define PH(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
@@ -35,8 +33,6 @@
 #define PH_T0() do {} while (0)
 #define PH(k) do {} while (0)
 #endif
-#define SOS_PRAGMA(x) _Pragma(#x)
-#define SOS_UNROLL(n) SOS_PRAGMA(unroll n)
 
 // Force a value the whole wave agrees on into scalar registers, so that the loop exits it decides are
 // uniform branches (keeps s / ig / operator pointers in SGPRs instead of per-lane VGPRs).
@@ -50,26 +46,32 @@ __device__ __forceinline__ double uniform_f64(double v)
 }
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// bitwise OR over the workgroup of up to 3 predicate bits (red: 4 ints of LDS); two barriers, no FP64 work.
+// bitwise OR over the workgroup of up to 3 predicate bits (red: NW ints of LDS); two barriers, no FP64 work.
 // (__syncthreads_or only returns a logical OR.)
-__device__ __forceinline__ int block_or_bits(int bits, int *red)
+template <int NW>
+__device__ __forceinline__ int block_or_bits(int bits, int *red, int wv, int lane)
 {
     int w = 0;
     if (__ballot(bits & 1)) w |= 1;
     if (__ballot(bits & 2)) w |= 2;
     if (__ballot(bits & 4)) w |= 4;
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    if (lane == 0) red[wv] = w;
     __syncthreads();
-    const int r = red[0] | red[1] | red[2] | red[3];
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r |= red[i];
     __syncthreads();
     return uniform_i32(r);
 }
 
-// FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak rates): every f64 VALU
-// instruction issued while the co-resident workgroup is contracting waits for a 64-cycle MFMA slot.  The stop
-// tests are therefore evaluated WITHOUT divisions and WITHOUT floating-point reductions: "max_k |y_k| > thr" is
-// the same decision as "exists k: |num_k| > thr |den_k|", reduced with one __syncthreads_or of predicate bits.
+// Instruction budget.  FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak
+// rates), and two workgroups share a CU, one wave of each per SIMD.  While one wave streams v_mfma_f64 (64 cycles
+// each, back to back) its partner gets roughly one vector-issue slot per MFMA: measured with phase stamps, every
+// non-MFMA vector instruction of the formal solution / write-back / tests costs 20-30 cycles in this regime
+// WHATEVER its kind.  The non-contraction phases are therefore written for the LOWEST VECTOR INSTRUCTION COUNT
+// (immediate offsets, wave-uniform control flow, no predicates, no divisions, no FP reductions), not for latency.
 //
+// Stop tests: "max_k |y_k| > thr" is the same decision as "exists k: |num_k| > thr |den_k|".
 // SOS_PARAM_CONV (SOS_OS.F:3434-3453): y = ((g/d - d/a) / (1 - g/d)^2) (g/x3) = (g a - d^2) d g / (a (d-g)^2 x3)
 // for a, d, x3 != 0.  (Differs from the quotient form only by rounding at the 1e-16 level of a 1e-5 threshold;
 // operands below ~1e-77 underflow in the products and are then ignored -- they are 1e-60 of the radiance scale.)
@@ -89,16 +91,9 @@ __device__ __forceinline__ double queue_term(double d, double g)
     return (d == 0.) ? 0. : (g * d) / (d - g);
 }
 
-// Instruction budget.  Two workgroups share a CU, one wave of each per SIMD.  While one wave streams
-// v_mfma_f64 (64 cycles each, back to back) its partner gets only the left-over vector-issue slots, and every
-// vector instruction of either wave delays the next MFMA.  Measured (phase stamps, profiles/): every non-MFMA VALU
-// instruction costs ~12-15 cycles in this regime whatever its kind, so the non-contraction phases are written for
-// the LOWEST VALU INSTRUCTION COUNT (running pointers, immediate offsets, no predicates, no divisions), not for
-// latency.
-//
-// Field storage convention: rows [0,KH) hold X(+mu), rows [KH,2KH) hold X(-mu) in half-system order
-// kk = c*N + (k-1), and the U component of the down-going half is stored NEGATED (V- = -U(-mu)).  With that the
-// parity combinations need no per-row sign:  X^A = X+ + X-,  X^B = X+ - X-,  S+ = E^A + E^B,  S- = E^A - E^B
+// Field storage convention: half-system order kk = c*N + (k-1) in both direction halves, and the U component of the
+// down-going half is stored NEGATED (V- = -U(-mu)).  With that the parity combinations need no per-row sign:
+//   X^A = X+ + X-,  X^B = X+ - X-,  S+ = E^A + E^B,  S- = E^A - E^B
 // (for U: X^A_U = U+ - U-, stored S-_U = -(E^B - E^A)); the formal solution is linear with a zero boundary for
 // down-going rows, so it maps a negated source to a negated field.  The sign is restored where U(-mu) leaves the
 // field: ground values (gnd) and output records.
@@ -107,53 +102,48 @@ __device__ __forceinline__ double queue_term(double d, double g)
 //   acc[sys] = XDEL o (M^sys X^sys)                                              (aerosol operator, dense)
 // plus, for s <= 2, the molecular operator in its exact rank-4 form on the one half system it acts on:
 //   acc[sr] += U (YDEL o (V^T X^sr))                                             (noyaux.hip k_pack_ray)
-// Each wave owns RTWH row tiles of BOTH systems x CT column tiles.
-template <int CT>
-__device__ __forceinline__ void b_fragments(v2d (&ba)[CT], v2d (&bb)[CT], const double *const (&bp)[CT], int KH, int m)
-{
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-        const v2d xp = *reinterpret_cast<const v2d *>(bp[ct] + 8 * m);
-        const v2d xm = *reinterpret_cast<const v2d *>(bp[ct] + KH + 8 * m);
-        ba[ct] = xp + xm;
-        bb[ct] = xp - xm;
-    }
-}
-
-template <int RTWH, int CT>
+// A wave works on NA (1 or 2) row tiles tile0, tile0 + NW of BOTH systems x CT column tiles; bx = its B-fragment
+// base (column lane&15, k-quad lane>>4) in the LDS field/staging buffer with level stride FS.
+template <int NA, int RTWH, int CT, int NW, int FS, int KHM>
 __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
                                             const double *__restrict__ vt, const double *__restrict__ uf, int ray_sys,
-                                            int ks2h, int rtph, int n2, const double *fld, int CS, int KH,
-                                            const double *xdel, const double *ydel, int lane, int wv)
+                                            int ks2h, int rtph, const double *bx, const double *xdel,
+                                            const double *ydel, int lane, int tile0)
 {
-    const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
-    const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
-    const double *bp[CT];
+    auto b_fragments = [&](v2d (&ba)[CT], v2d (&bb)[CT], int m) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) bp[ct] = fld + (size_t)(ct * 16 + (lane & 15)) * CS + 2 * (lane >> 4);
+        for (int ct = 0; ct < CT; ct++) {
+            const v2d xp = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + 8 * m);
+            const v2d xm = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + KHM + 8 * m);
+            ba[ct] = xp + xm;
+            bb[ct] = xp - xm;
+        }
+    };
     if (do_aer) {
-        const v2d *ap = reinterpret_cast<const v2d *>(mp) + ((size_t)(wv * RTWH) * ks2h) * 64 + lane;
+        const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
+        const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
+        const v2d *ap = reinterpret_cast<const v2d *>(mp) + (size_t)tile0 * rts + lane;
         // two register sets of A fragments used alternately (k-pair m from one set while m+1 loads into the other):
         // no register-to-register copies in the loop
-        v2d a0[2][RTWH], a1[2][RTWH];
-        auto load_a = [&](v2d (&a)[2][RTWH], int m) {
+        v2d a0[2][NA], a1[2][NA];
+        auto load_a = [&](v2d (&a)[2][NA], int m) {
 #pragma unroll
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                for (int rt = 0; rt < RTWH; rt++) a[sy][rt] = ap[sy * sys_stride + rt * rts + (size_t)m * 64];
+                for (int rt = 0; rt < NA; rt++) a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
         };
-        auto mma = [&](const v2d (&a)[2][RTWH], int m) {
+        auto mma = [&](const v2d (&a)[2][NA], int m) {
             v2d ba[CT], bb[CT];
-            b_fragments<CT>(ba, bb, bp, KH, m);
+            b_fragments(ba, bb, m);
 #pragma unroll
-            for (int rt = 0; rt < RTWH; rt++)
+            for (int rt = 0; rt < NA; rt++)
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
                     acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
                     acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
                 }
 #pragma unroll
-            for (int rt = 0; rt < RTWH; rt++)
+            for (int rt = 0; rt < NA; rt++)
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
                     acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
@@ -177,12 +167,12 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                for (int rt = 0; rt < RTWH; rt++) acc[sy][rt][ct] *= sc;
+                for (int rt = 0; rt < NA; rt++) acc[sy][rt][ct] *= sc;
         }
     }
     if (ray_sys >= 0) {
         // projections pr = V^T X^sr: one 16-row tile (rows 0..3 used) per column tile, every wave computes them itself
-        // (64 MFMAs instead of the 256 of a dense pass, and no cross-wave exchange)
+        // (2 CT KS2H MFMAs instead of a second dense pass, and no cross-wave exchange)
         const v2d *vp = reinterpret_cast<const v2d *>(vt) + lane;
         v4d pr[CT];
 #pragma unroll
@@ -191,7 +181,7 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
         for (int m = 0; m < ks2h; m++) {
             const v2d a = vp[(size_t)m * 64];
             v2d ba[CT], bb[CT];
-            b_fragments<CT>(ba, bb, bp, KH, m);
+            b_fragments(ba, bb, m);
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const v2d b = ray_sys ? bb[ct] : ba[ct];
@@ -205,8 +195,8 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
         for (int ct = 0; ct < CT; ct++) {
             const double q = pr[ct][0] * ydel[ct * 16 + (lane & 15)];
 #pragma unroll
-            for (int rt = 0; rt < RTWH; rt++) {
-                const double u = uf[(size_t)(wv * RTWH + rt) * 64 + lane];
+            for (int rt = 0; rt < NA; rt++) {
+                const double u = uf[(size_t)(tile0 + rt * NW) * 64 + lane];
                 if (ray_sys) acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[1][rt][ct], 0, 0, 0);
                 else acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[0][rt][ct], 0, 0, 0);
             }
@@ -214,65 +204,86 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
     }
 }
 
+// Capacity constants of a variant (shared by the kernel and the host-side sizing below).
+//   KHM = rows per direction half (3N <= KHM), FS = level stride of the field, NS = row stride of the attenuation table
+__host__ __device__ constexpr int sos_khm(int nw, int rtwh) { return 16 * nw * rtwh; }
+__host__ __device__ constexpr int sos_fs(int nw, int rtwh) { return 2 * sos_khm(nw, rtwh) + 2; }
+__host__ __device__ constexpr int sos_ns(int nw, int rtwh) { return (sos_khm(nw, rtwh) / 3 + 1) & ~1; }
+
+// One level of the formal solution (SOS_INTEGR_EPOPT, SOS_OS.F:2279-2354).  With t = exp(-dtau/|mu|) and the source
+// linear in tau on the layer, both directions reduce to the same three-term recurrence
+//     X_i = t X_n + p S_i + w S_n,   w = (1-t) |mu|/dtau - t,  p = (1-t) - w
+// (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), algebraically the reference update
+// X t + (1-t)(a mu + b) -/+ a t dtau.  7 FP64 instructions per level, one of them on the dependent chain.
+#define SOS_LEVEL(SRC, DST, A, IDT)                                       \
+    {                                                                    \
+        const double a_ = (A), si_ = (SRC), r_ = mu * (IDT);             \
+        const double omt_ = 1.0 - a_;                                    \
+        const double w_ = omt_ * r_ - a_;                                \
+        const double pq_ = omt_ - w_;                                    \
+        z = z * a_ + (pq_ * si_ + w_ * sn);                              \
+        (DST) = z;                                                       \
+        sn = si_;                                                        \
+    }
+
+// NW   : waves per workgroup (4: N <= 42, 8: N <= 85); waves [0,NW/2) hold up-going rows, the rest down-going rows
+// RTWH : row tiles per wave and half system (tile = wave + rt*NW)
+// CT   : column tiles (16 levels each) held in LDS at once
 // BIG = false: the whole field (NT+1 <= 16*CT levels) lives in LDS.
 // BIG = true : the field, the attenuation table and the level vectors live in a per-bin HBM/L2 scratch
 //              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of
-//              16*CT levels staged through LDS, the formal solution streams the scratch with batched loads.
-// ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- tracks two extra levels per row.
-// Register bound: 256 architectural VGPRs for every variant (two workgroups per CU when the LDS allows it).  The
-// 512-register form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded
-// form with a few scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one of its instantiations
-// (<2,4,false,true> with a 4-level scan block) produced wrong down-going rows on gfx950, so it is not used.
-template <int RTWH, int CT, bool BIG, bool ZO>
-__global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBins bn)
+//              16*CT levels staged through LDS, the formal solution streams the scratch.
+// ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- two extra levels per row are
+//             read back from the field after every formal solution.
+// Register bound: 256 architectural VGPRs (two workgroups per CU for NW = 4 when the LDS allows it).  The 512-register
+// form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded form with a few
+// scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one instantiation gave wrong down-going rows on
+// gfx950, so it is not used.
+template <int NW, int RTWH, int CT, bool BIG, bool ZO>
+__global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
+    constexpr int NTH = 64 * NW, HW = NW / 2;
     constexpr int COLS = 16 * CT;
-#ifdef SOS_SCAN_UNROLL_FORCE
-    constexpr int SU = SOS_SCAN_UNROLL_FORCE;
-#else
-    constexpr int SU = 4;                        // formal-solution unroll
-#endif
-    const int N = cx.n, R6 = cx.r6, KP = cx.kp, KH = cx.kh, CS = 2 * cx.kh + 2, W = cx.w;
+    constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
+    const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
     const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
-    const int FS = BIG ? 2 * cx.kh : CS;   // level stride of the field storage
-    double *cbuf = smem;                   // [COLS][CS]  LDS: the field itself, or the staging chunk (BIG)
-    double *gnd = cbuf + COLS * CS;        // [3][N] down-going field at the ground, order ig-1
-    double *i3s = gnd + 3 * N;             // [2N]   I3 of the I rows (flux integrals)
-    double *red = i3s + 2 * N;             // [16]
-    double *lga = red + 16;                // [N] Gauss weights, [N] mu (LDS copies for the ground-reflection sums)
-    double *lmu = lga + N;
-    double *sbase = BIG ? bn.scratch + (size_t)blockIdx.x * bn.scr_stride : lmu + N;
+    double *cbuf = smem;                   // [COLS][FS]  LDS: the field itself, or the staging chunk (BIG)
+    double *gnd = cbuf + COLS * FS;        // [3][NS] down-going field at the ground, order ig-1
+    double *i3s = gnd + 3 * NS;            // [2][NS] I3 of the I rows (flux integrals)
+    double *red = i3s + 2 * NS;            // [16]
+    double *lga = red + 16;                // [NS] Gauss weights, [NS] mu (LDS copies for the ground-reflection sums)
+    double *lmu = lga + NS;
+    double *sbase = BIG ? bn.scratch + (size_t)blockIdx.x * bn.scr_stride : lmu + NS;
     double *fld = BIG ? sbase : cbuf;      // [LPB][FS]   field / source, [level][+mu rows | -mu rows]
-    double *att = BIG ? sbase + (size_t)LPB * FS : sbase;   // [LPB][N] exp(-dtau_i/mu_j), layer i = levels i..i+1
-    double *dtau = att + (size_t)LPB * N;  // [LPB] each:
-    double *idtau = dtau + LPB;
+    double *att = BIG ? sbase + (size_t)LPB * FS : sbase;   // [LPB][NS] exp(-dtau_i/mu_j), layer i = levels i..i+1
+    double *idtau = att + (size_t)LPB * NS;  // [LPB] each:
     double *xdel = idtau + LPB;
     double *ydel = xdel + LPB;
-    double *ch = ydel + LPB;
-    double *fco = ch + LPB;
-    double *hh = fco + LPB;
+    double *cxd = ydel + LPB;              // order-1 level factors: exp(-h/mus)/4 * XDEL, * YDEL
+    double *cyd = cxd + LPB;
+    double *fxd = cyd + LPB;               // Fresnel order-1 level factors (hold dtau / h during the set-up)
+    double *fyd = fxd + LPB;
 
-#ifdef SOS_STATIC_PRIO
-    // Two workgroups share a CU (one wave of each per SIMD).  Give the one whose LDS allocation starts at 0 a
-    // higher static priority: it wins the matrix pipe whenever both want it, so the pair settles in anti-phase
-    // (one contracting while the other runs its formal solution) instead of sharing the pipe and then idling it.
-    if ((__builtin_amdgcn_s_getreg(0x3806) & 0xff) == 0) __builtin_amdgcn_s_setprio(SOS_STATIC_PRIO);
-#endif
-    // thread -> state row: t < 3N up-going (+mu), 3N <= t < 6N down-going; kk = c*N + jj in both halves
+    // thread -> state row: waves [0,HW) up-going (+mu), waves [HW,NW) down-going; kk = c*N + jj in both halves
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool active = t < R6;
-    const bool up = t < 3 * N;
-    const int kk = active ? (up ? t : t - 3 * N) : 0;
+    const bool up = wv < HW;               // wave-uniform
+    const int kk0 = up ? t : t - 64 * HW;
+    const bool active = kk0 < 3 * N;
+    const int kk = active ? kk0 : 0;
     const int c = kk / N;
     const int jj = kk % N;                 // 0-based index of |direction|
     const int d = up ? jj : N + jj;
-    const int rl = up ? kk : KH + kk;      // LDS row of this thread
+    const int rl = up ? kk : KHM + kk;     // field row of this thread
     const int rsv = c * 2 * N + d;         // row in the order-1 vector tables (sv)
     const double mu = cx.mu[jj];
     const int recoff = c * W + N + (up ? (jj + 1) : -(jj + 1));
     const size_t mper = (size_t)2 * cx.rtph * cx.ks2h * 128;
     const int S1 = cx.smax + 1;
+    // contraction tiles of this wave: tile wv, and tile wv + NW for the larger N of a variant (wave-uniform)
+    const bool tile_a = wv * 16 < KH;
+    const bool tile_b = RTWH > 1 && (wv + NW) * 16 < KH;
+    const double *bx = cbuf + (lane & 15) * FS + 2 * (lane >> 4);
 
     {   // one workgroup = one bin (grid = nb): no bin loop, so per-bin constants are not kept live elsewhere
         const int b = blockIdx.x;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
         const int iborm = uniform_i32(bn.iborm[b]);
         const int jout = ZO ? uniform_i32(bn.jout ? bn.jout[b] : 0) : 0;
         const double zz = ZO ? uniform_f64(jout ? bn.zz[b] : 0.) : 0.;
-        const int jlo = (ZO && jout) ? jout - 1 : -1, jhi = (ZO && jout) ? jout : -1;
+        const int jlo = (ZO && jout) ? jout - 1 : 0, jhi = (ZO && jout) ? jout : 0;
         // shape guard (uniform): a malformed bin is flagged (norders = -1), never indexed out of bounds
         if (nt < 1 || nt >= LPB || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
             if (t == 0) bn.norders[b] = -1;
@@ -291,8 +302,10 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
 
         __syncthreads();
         if (t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
-        for (size_t i = t; i < (size_t)LPB * FS; i += 256) fld[i] = 0.;
-        for (int i = t; i < LPB; i += 256) {
+        for (size_t i = t; i < (size_t)LPB * FS; i += NTH) fld[i] = 0.;
+        if (BIG) for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
+        double *hh = fyd, *dtau = fxd;         // set-up only: these two slots end up holding the Fresnel factors
+        for (int i = t; i < LPB; i += NTH) {
             const bool in = i <= nt;
             hh[i] = in ? pf[i] : 0.;
             xdel[i] = in ? pf[bn.lp + i] : 0.;
@@ -300,72 +313,72 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
         }
         __syncthreads();
         const double htot = uniform_f64(hh[nt]);
+        const double h0 = uniform_f64(hh[0]);
+        const double hlo = uniform_f64(hh[jlo]), hhi = uniform_f64(hh[jhi]);
         int aer_l = 0;
-        for (int i = t; i < LPB; i += 256) {
-            if (i < nt) { const double dt = hh[i + 1] - hh[i]; dtau[i] = dt; idtau[i] = 1.0 / dt; }
-            else { dtau[i] = 0.; idtau[i] = 0.; }
-            ch[i] = (i <= nt) ? exp(-hh[i] / cx.mus) / 4. : 0.;                               // SOS_OS.F:837-839
-            fco[i] = (i <= nt) ? (exp(-2. * htot / cx.mus) / 4.) * exp(hh[i] / cx.mus) : 0.;  // SOS_OS.F:3219,3278
+        for (int i = t; i < LPB; i += NTH) {
+            const double dt = (i < nt) ? hh[i + 1] - hh[i] : 0.;
+            dtau[i] = dt;
+            idtau[i] = (i < nt) ? 1.0 / dt : 0.;
+            const double ch = (i <= nt) ? exp(-hh[i] / cx.mus) / 4. : 0.;                               // SOS_OS.F:837-839
+            cxd[i] = ch * xdel[i]; cyd[i] = ch * ydel[i];
             if (i <= nt && xdel[i] != 0.) aer_l = 1;
         }
         const int has_aer = uniform_i32(__syncthreads_or(aer_l));
-        for (int i = t; i < nt * N; i += 256) att[i] = exp(-dtau[i / N] / cx.mu[i % N]);      // SOS_OS.F:2291,2335
+        for (int i = t; i < nt * N; i += NTH) att[(i / N) * NS + i % N] = exp(-dtau[i / N] / cx.mu[i % N]);   // SOS_OS.F:2291,2335
+        __syncthreads();
+        for (int i = t; i < LPB; i += NTH) {   // own elements only: h_i -> fco_i XDEL_i | fco_i YDEL_i
+            const double fco = (i <= nt) ? (exp(-2. * htot / cx.mus) / 4.) * exp(hh[i] / cx.mus) : 0.;  // SOS_OS.F:3219,3278
+            fxd[i] = fco * xdel[i]; fyd[i] = fco * ydel[i];
+        }
         // bin-constant exponentials of the ground boundary terms (SOS_OS.F:979,985,1068-1077)
         const double e_sun = uniform_f64(exp(-htot / cx.mus));
         double e_mu = 0., e_lo = 0., e_hi = 0.;
         if (cx.imat_surf && active && up) {
             e_mu = exp(-htot / mu);
-            e_lo = exp(-(htot - hh[0]) / mu);     // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
-            if (ZO && jout) { e_lo = exp(-(htot - hh[jlo]) / mu); e_hi = exp(-(htot - hh[jhi]) / mu); }
+            e_lo = exp(-(htot - h0) / mu);        // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
+            if (ZO && jout) { e_lo = exp(-(htot - hlo) / mu); e_hi = exp(-(htot - hhi) / mu); }
         }
         __syncthreads();
 
-        // per-thread formal solution of its row, in place over the source held in fld (SOS_INTEGR_EPOPT,
-        // SOS_OS.F:2279-2354).  bcv = value at the ground for up-going rows.  With t = exp(-dtau/|mu|) and the
-        // source linear in tau on the layer, both directions reduce to the same three-term recurrence
-        //     X_i = t X_n + p S_i + w S_n,   w = (1-t) |mu|/dtau - t,  p = (1-t) - w
-        // (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), algebraically the
-        // reference update X t + (1-t)(a mu + b) -/+ a t dtau.  Up- and down-going rows share ONE instruction stream
-        // (per-lane start level and stride), all addresses are running pointers: ~11 vector instructions per level.
+        // per-thread formal solution of its row, in place over the source held in fld.  bcv = value at the ground for
+        // up-going rows.  The sweep direction DI is a template argument (wave-uniform): blocks of 8/4/2/1 levels with
+        // all field / attenuation / 1/dtau addresses as immediate offsets from three base registers.
         const double usign = (c == 2 && !up) ? -1. : 1.;     // U(-mu) is stored negated (see gemm_source)
-        double xb, xlo = 0., xhi = 0.;
-        auto scan_row = [&](double bcv) {
-            if (!active) { xb = 0.; return; }
-            const int i0 = up ? nt : 0;                 // level the ray starts from
-            const int di = up ? -1 : 1;
-            const int lay0 = up ? nt - 1 : 0;           // first layer crossed; the layer index moves with di
-            double *sp = fld + (size_t)i0 * FS + rl;
-            const ptrdiff_t sst = (ptrdiff_t)di * FS;
-            const double *ap = att + lay0 * N + jj;
-            const int ast = di * N;
-            const double *dp = dtau + lay0;             // idtau = dtau + LPB
-            double z = up ? bcv : 0.;
-            double sn = *sp;                            // source at the level the ray comes from
-            *sp = z;
-            if (ZO) { if (i0 == jlo) xlo = z; if (i0 == jhi) xhi = z; }
-            int lev = i0;
-            auto level = [&]() {
-                sp += sst;
-                const double a = *ap, si = *sp, r = mu * dp[LPB];
-                const double omt = 1.0 - a;
-                const double w = omt * r - a;
-                const double pq = omt - w;
-                z = z * a + (pq * si + w * sn);
-                *sp = z;
-                sn = si;
-                ap += ast; dp += di;
-                if (ZO) { lev += di; if (lev == jlo) xlo = z; if (lev == jhi) xhi = z; }
+        double xb = 0., xlo = 0., xhi = 0.;
+        auto scan_dir = [&](auto dir_tag, double bcv) {
+            constexpr int DI = decltype(dir_tag)::value;
+            // q  -> field at the level the ray has reached, qa -> attenuation of the next layer, qd -> its 1/dtau
+            double *q = fld + (size_t)(DI < 0 ? nt : 0) * FS + rl;
+            const double *qa = att + (size_t)(DI < 0 ? nt - 1 : 0) * NS + jj;
+            const double *qd = idtau + (DI < 0 ? nt - 1 : 0);
+            double z = bcv;
+            double sn = *q;                             // source at the level the ray comes from
+            *q = z;
+            auto block = [&](auto cnt_tag) {
+                constexpr int U = decltype(cnt_tag)::value;
+#pragma unroll
+                for (int u = 0; u < U; ++u) SOS_LEVEL(q[DI * (u + 1) * FS], q[DI * (u + 1) * FS], qa[DI * u * NS], qd[DI * u])
+                q += DI * U * FS; qa += DI * U * NS; qd += DI * U;
             };
             int k = 0;
 #pragma unroll 1
-            for (; k + SU <= nt; k += SU) {             // exact trip counts: blocks of SU levels, then the tail
-#pragma unroll
-                for (int u = 0; u < SU; ++u) level();
-            }
-#pragma unroll 1
-            for (; k < nt; ++k) level();
+            for (; k + 8 <= nt; k += 8) block(std::integral_constant<int, 8>());
+            if (nt & 4) block(std::integral_constant<int, 4>());
+            if (nt & 2) block(std::integral_constant<int, 2>());
+            if (nt & 1) block(std::integral_constant<int, 1>());
             xb = z;
-            if (!up) gnd[c * N + jj] = z * usign;
+        };
+        auto scan_row = [&](double bcv) {
+            if (up) {
+                if (active) scan_dir(std::integral_constant<int, -1>(), bcv);
+            } else {
+                if (active) {
+                    scan_dir(std::integral_constant<int, 1>(), 0.);
+                    gnd[c * NS + jj] = xb * usign;
+                }
+            }
+            if (ZO && jout && active) { xlo = fld[(size_t)jlo * FS + rl]; xhi = fld[(size_t)jhi * FS + rl]; }
         };
 
         double i4 = 0., i5 = 0.;
@@ -398,30 +411,44 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
                     for (int j = 0; j < N; j++) {
                         double q0 = r0[j], q1 = r1[j], q2 = r2[j];
                         if (!cx.ipolar) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }   // SOS_OS.F:928-941
-                        acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[N + j] * q1 + gnd[2 * N + j] * q2);
+                        acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[NS + j] * q1 + gnd[2 * NS + j] * q2);
                     }
                     v = acc2 * (2 / mu) + xr;
                 }
                 if (cx.ifresnel == 1) {
                     const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
-                    if (c == 0) v = v + f11 * gnd[jj] + f12 * gnd[N + jj];
-                    else if (c == 1) v = v + f12 * gnd[jj] + f11 * gnd[N + jj];
-                    else v = v + f33 * gnd[2 * N + jj];
+                    if (c == 0) v = v + f11 * gnd[jj] + f12 * gnd[NS + jj];
+                    else if (c == 1) v = v + f12 * gnd[jj] + f11 * gnd[NS + jj];
+                    else v = v + f33 * gnd[2 * NS + jj];
                 }
                 return v;
             };
 
-            // ---- scattering order 1 ------------------------------------------------------------
+            // ---- scattering order 1: source (SOS_FSOURCE_ORDRE1) ---------------------------------
+            // S1_i = exp(-h_i/mus)/4 (sva XDEL_i + svr YDEL_i) [+ Fresnel-reflected beam term], SOS_OS.F:2557-2559,
+            // 3280-3289; the level factors are per-bin tables, the row factors carry the storage sign of U(-mu).
             const double *svp = cx.sv + (size_t)s * 4 * KP;
             if (active) {
-                const double sva = svp[rsv], svr = svp[KP + rsv];
-                const double sfa = svp[2 * KP + rsv], sfr = svp[3 * KP + rsv];
+                const double sva = svp[rsv] * usign, svr = svp[KP + rsv] * usign;
+                double *q = fld + rl;
+                if (cx.ifresnel == 1) {
+                    const double sfa = svp[2 * KP + rsv] * usign, sfr = svp[3 * KP + rsv] * usign;
 #pragma unroll 1
-                for (int i = 0; i <= nt; i++) {
-                    double v = ch[i] * (sva * xdel[i] + svr * ydel[i]);              // SOS_OS.F:2557-2559
-                    if (cx.ifresnel == 1 && (up ? (i < nt) : (i >= 1)))
-                        v = v + fco[i] * (sfa * xdel[i] + sfr * ydel[i]);            // SOS_OS.F:3280-3289
-                    fld[(size_t)i * FS + rl] = v * usign;
+                    for (int i = 0; i <= nt; i++) {
+                        double v = sva * cxd[i] + svr * cyd[i];
+                        if (up ? (i < nt) : (i >= 1)) v = v + (sfa * fxd[i] + sfr * fyd[i]);
+                        q[(size_t)i * FS] = v;
+                    }
+                } else {
+                    int i = 0;
+#pragma unroll 1
+                    for (; i + 8 <= nt + 1; i += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) q[u * FS] = sva * cxd[i + u] + svr * cyd[i + u];
+                        q += 8 * FS;
+                    }
+#pragma unroll 1
+                    for (; i <= nt; i++) { *q = sva * cxd[i] + svr * cyd[i]; q += FS; }
                 }
             }
             double bc = 0., dirterm = 0.;
@@ -436,28 +463,57 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
                     dirterm = bc - xr;                                               // SOS_OS.F:1070-1072
                 }
             }
-            PH(0);
-            scan_row(bc);
-            PH(1);
             double rii = 0., riilo = 0., riihi = 0.;
             if (cx.imat_surf && active && up) {                                      // SOS_OS.F:1062-1084
                 rii = e_mu * dirterm;
                 riilo = e_lo * dirterm;
                 if (ZO) riihi = e_hi * dirterm;
             }
-            double i3 = xb, a1 = 0., d1 = xb, g1 = 0.;                               // SOS_OS.F:1094-1137
-            double i3lo = ZO ? xlo : 0., dlo = i3lo, i3hi = ZO ? xhi : 0., dhi = i3hi;
-            __syncthreads();
-            bc = ground_bc();
-            PH(5);
+            PH(0);
 
-            // ---- scattering orders >= 2 --------------------------------------------------------
+            // ---- scattering orders: formal solution of the current source, stop tests, next source ----------
+            double i3 = 0., a1 = 0., d1 = 0., g1 = 0.;
+            double i3lo = 0., dlo = 0., i3hi = 0., dhi = 0.;
             int ig = 1, iglast = 1;
             for (;;) {
+                scan_row(bc);                                                        // SOS_OS.F:1025 / 1244
+                __syncthreads();
+                PH(1);
+                if (ig == 1) {                                                       // SOS_OS.F:1094-1137
+                    i3 = xb; a1 = 0.; d1 = xb; g1 = 0.;
+                    if (ZO) { i3lo = xlo; dlo = xlo; i3hi = xhi; dhi = xhi; }
+                    bc = ground_bc();
+                    PH(5);
+                } else {
+                    g1 = xb;
+                    const double i3n = i3 + g1;
+                    int pm = 0;
+                    if (active) {
+                        if (ig != 2 && conv_exceeds(a1, d1, g1, i3, cx.thr_cv)) pm |= 1;     // SOS_PARAM_CONV
+                        const double ag = fabs(g1);
+                        if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
+                        if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
+                    }
+                    pm = block_or_bits<NW>(pm, reinterpret_cast<int *>(red), wv, lane);
+                    PH(4);
+                    bc = ground_bc();
+                    PH(5);
+                    if (ig != 2 && !(pm & 1)) {                                          // SOS_OS.F:1293-1315
+                        i3 = i3 + queue_term(d1, g1);
+                        if (ZO) { i3lo = i3lo + queue_term(dlo, xlo); i3hi = i3hi + queue_term(dhi, xhi); }
+                        break;
+                    }
+                    a1 = d1; d1 = g1;                                                    // SOS_OS.F:1323-1363
+                    i3 = i3n;
+                    if (ZO) { dlo = xlo; dhi = xhi; i3lo = i3lo + xlo; i3hi = i3hi + xhi; }
+                    if (!(pm & 2)) break;                                                // SOS_OS.F:1370
+                    if (!(pm & 4)) break;                                                // SOS_OS.F:1389
+                    if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
+                }
                 ig = ig + 1;
                 if (ig > cx.igmax) break;
                 iglast = ig;
-                // source function: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
+                // source function of order ig: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
                 const int nchunk = BIG ? (nt + COLS) / COLS : 1;
 #pragma unroll 1
                 for (int chk = 0; chk < nchunk; chk++) {
@@ -469,85 +525,63 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
                         for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
                             for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
-                    __syncthreads();
                     if (BIG) {                                 // stage the chunk: scratch -> LDS (16 B per lane, coalesced)
-                        const int per_lev = KH;                // v2d per level (2*KH doubles)
-                        for (int q = t; q < COLS * per_lev; q += 256) {
-                            const int col = q / per_lev, r2 = q % per_lev;
+                        __syncthreads();
+                        for (int q = t; q < COLS * KH; q += NTH) {
+                            const int col = q / KH, r = q % KH;                    // v2d index r within [X+ | X-]
+                            const int row = (r < KH / 2) ? 2 * r : KHM + 2 * r - KH;
                             v2d v = {0., 0.};
-                            if (l0 + col <= nt) v = *reinterpret_cast<const v2d *>(fld + (size_t)(l0 + col) * FS + 2 * r2);
-                            *reinterpret_cast<v2d *>(cbuf + (size_t)col * CS + 2 * r2) = v;
+                            if (l0 + col <= nt) v = *reinterpret_cast<const v2d *>(fld + (size_t)(l0 + col) * FS + row);
+                            *reinterpret_cast<v2d *>(cbuf + (size_t)col * FS + row) = v;
                         }
                         __syncthreads();
                     }
-                    gemm_source<RTWH, CT>(acc, cx.mp_aer + (size_t)s * mper, has_aer != 0,
-                                          cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128,
-                                          cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64, s <= 2 ? (s & 1) : -1,
-                                          cx.ks2h, cx.rtph, 2 * N, cbuf, CS, KH, xdel + l0, ydel + l0, lane, wv);
+                    const double *mpa = cx.mp_aer + (size_t)s * mper;
+                    const double *vtp = cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128;
+                    const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
+                    const int ray_sys = s <= 2 ? (s & 1) : -1;
+                    if (tile_b)
+                        gemm_source<RTWH, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, ray_sys, cx.ks2h, cx.rtph,
+                                                                 bx, xdel + l0, ydel + l0, lane, wv);
+                    else if (tile_a)
+                        gemm_source<1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, ray_sys, cx.ks2h, cx.rtph,
+                                                              bx, xdel + l0, ydel + l0, lane, wv);
                     __syncthreads();
                     PH(2);
                     // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
                     // accumulators are exact zeros (zero operator rows, zero field columns) and are stored as such.
                     {
-                        double *wb = cbuf + (size_t)(lane & 15) * CS + (wv * RTWH) * 16 + (lane >> 4);
+                        double *wb = cbuf + (lane & 15) * FS + (lane >> 4);
 #pragma unroll
-                        for (int ct = 0; ct < CT; ct++) {
-                            double *wp = wb + (size_t)ct * 16 * CS, *wm = wp + KH;
+                        for (int rt = 0; rt < RTWH; rt++) {
+                            const int tile = wv + rt * NW;
+                            // rows of this tile inside the half system (KH is a multiple of 8, register e holds
+                            // rows 4e..4e+3 of the tile): a wave-uniform count, no lane predicate
+                            const int ne = (KH - tile * 16) >> 2;
 #pragma unroll
-                            for (int rt = 0; rt < RTWH; rt++) {
-                                // rows of this tile inside the half system (KH is a multiple of 8, register e holds
-                                // rows 4e..4e+3 of the tile): a wave-uniform count, no lane predicate
-                                const int ne = (KH - (wv * RTWH + rt) * 16) >> 2;
+                            for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                                 for (int e = 0; e < 4; e++)
                                     if (e < ne) {
                                         const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
-                                        wp[rt * 16 + 4 * e] = ea + eb;
-                                        wm[rt * 16 + 4 * e] = ea - eb;
+                                        wb[ct * 16 * FS + tile * 16 + 4 * e] = ea + eb;
+                                        wb[ct * 16 * FS + KHM + tile * 16 + 4 * e] = ea - eb;
                                     }
-                            }
                         }
                     }
                     __syncthreads();
                     if (BIG) {                                 // source chunk: LDS -> scratch
-                        const int per_lev = KH;
-                        for (int q = t; q < COLS * per_lev; q += 256) {
-                            const int col = q / per_lev, r2 = q % per_lev;
+                        for (int q = t; q < COLS * KH; q += NTH) {
+                            const int col = q / KH, r = q % KH;
+                            const int row = (r < KH / 2) ? 2 * r : KHM + 2 * r - KH;
                             if (l0 + col <= nt)
-                                *reinterpret_cast<v2d *>(fld + (size_t)(l0 + col) * FS + 2 * r2) =
-                                    *reinterpret_cast<const v2d *>(cbuf + (size_t)col * CS + 2 * r2);
+                                *reinterpret_cast<v2d *>(fld + (size_t)(l0 + col) * FS + row) =
+                                    *reinterpret_cast<const v2d *>(cbuf + (size_t)col * FS + row);
                         }
                     }
                 }
-                __syncthreads();
+                if (BIG) __syncthreads();
                 PH(3);
-                scan_row(bc);                                                        // SOS_OS.F:1244
-                __syncthreads();
-                PH(1);
-                g1 = xb;
-                const double i3n = i3 + g1;
-                int pm = 0;
-                if (active) {
-                    if (ig != 2 && conv_exceeds(a1, d1, g1, i3, cx.thr_cv)) pm |= 1;     // SOS_PARAM_CONV
-                    const double ag = fabs(g1);
-                    if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
-                    if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
-                }
-                pm = block_or_bits(pm, reinterpret_cast<int *>(red));
-                PH(4);
-                bc = ground_bc();
-                PH(5);
-                if (ig != 2 && !(pm & 1)) {                                          // SOS_OS.F:1293-1315
-                    i3 = i3 + queue_term(d1, g1);
-                    if (ZO) { i3lo = i3lo + queue_term(dlo, xlo); i3hi = i3hi + queue_term(dhi, xhi); }
-                    break;
-                }
-                a1 = d1; d1 = g1;                                                    // SOS_OS.F:1323-1363
-                i3 = i3n;
-                if (ZO) { dlo = xlo; dhi = xhi; i3lo = i3lo + xlo; i3hi = i3hi + xhi; }
-                if (!(pm & 2)) break;                                                // SOS_OS.F:1370
-                if (!(pm & 4)) break;                                                // SOS_OS.F:1389
-                if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
             }
             // SOS_OS.F:1421-1439.  The record is built from I3OUT (minus RIIOUT at the output level), the stop
             // tests and fluxes from I3 (minus RII): the two differ by exp(H(0)/mu) on the direct term.
@@ -558,12 +592,12 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
             }
 
             if (s == 0) {                                                            // SOS_OS.F:1447-1456
-                if (active && c == 0) i3s[d] = i3;
+                if (active && c == 0) i3s[up ? jj : NS + jj] = i3;
                 __syncthreads();
                 if (t == 0) {
                     double em = 0., ep = 0.;
                     for (int j = 0; j < N; j++) {
-                        em = em + lmu[j] * lga[j] * i3s[N + j];
+                        em = em + lmu[j] * lga[j] * i3s[NS + j];
                         ep = ep + lmu[j] * lga[j] * i3s[j];
                     }
                     bn.flux[2 * b] = em * 2 / cx.mus;
@@ -580,18 +614,18 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
             }
             if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
             nord = s + 1;
-            int pf = 0;                                                              // SOS_ARRET_FOURIER
+            int pf2 = 0;                                                             // SOS_ARRET_FOURIER
             if (active) {
                 const double a3 = fabs(i3);
-                if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf = 1;
+                if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf2 = 1;
             }
-            pf = block_or_bits(pf, reinterpret_cast<int *>(red));
+            pf2 = block_or_bits<NW>(pf2, reinterpret_cast<int *>(red), wv, lane);
             PH(6);
-            if (!pf) break;                                                          // SOS_OS.F:1585
+            if (!pf2) break;                                                         // SOS_OS.F:1585
         }
         // orders not run: zero records and counts
-        for (int i = t + nord * 3 * W; i < S1 * 3 * W; i += 256) recb[i] = 0.;
-        for (int i = t + nord; i < S1; i += 256) bn.iglast[(size_t)b * S1 + i] = 0;
+        for (int i = t + nord * 3 * W; i < S1 * 3 * W; i += NTH) recb[i] = 0.;
+        for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
         if (t == 0) bn.norders[b] = nord;
 #ifdef SOS_PROFILE_PHASES
         if (bn.phase && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&bn.phase[(size_t)b * 8 + k], ph_acc[k]);
@@ -602,28 +636,28 @@ __global__ __launch_bounds__(256, 2) void k_sos_os(const SosDev cx, const SosBin
 // ---------------------------------------------------------------------------------------------
 // variant table
 // ---------------------------------------------------------------------------------------------
-static size_t lds_bytes_for(int n, int ct, bool big)
+static size_t lds_bytes_for(int nw, int rtw, int ct, bool big)
 {
-    const int cols = 16 * ct;
-    const int kh = sos_round_up(3 * n, 8);
-    size_t dbl = (size_t)cols * (2 * kh + 2) + 3 * n + 2 * n + 16 + 2 * n;
-    if (!big) dbl += (size_t)cols * n + 7 * cols;
+    const int cols = 16 * ct, fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw);
+    size_t dbl = (size_t)cols * fs + 3 * ns + 2 * ns + 16 + 2 * ns;
+    if (!big) dbl += (size_t)cols * ns + 7 * cols;
     return dbl * sizeof(double);
 }
 
-// returns 0 and the variant (rtw = row tiles per wave and system, ct = column tiles, big) or UNSUPPORTED
-int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes, int *big)
+// returns 0 and the variant (nw waves, rtw row tiles per wave and system, ct column tiles, big) or UNSUPPORTED
+int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_bytes, int *big)
 {
     if (n < 1 || n > 85 || nt_max < 1 || nt_max > 1023) return SOSGPU_E_UNSUPPORTED;
     const int kh = sos_round_up(3 * n, 8);
-    const int rth = (kh + 15) / 16;
-    const int r = (rth + 3) / 4;
-    int c = 0, b = 0;
-    if (nt_max + 1 <= 32 && lds_bytes_for(n, 2, false) <= 160 * 1024) c = 2;
-    else if (nt_max + 1 <= 64 && r <= 3 && lds_bytes_for(n, 4, false) <= 160 * 1024 && !getenv("SOSGPU_DEBUG_FORCE_BIG")) c = 4;
-    else { c = 2; b = 1; }
-    const size_t lb = lds_bytes_for(n, c, b);
+    const int w = kh <= 128 ? 4 : 8;
+    const int r = kh <= 64 ? 1 : 2;
+    int c = 2, b = 0;
+    if (nt_max + 1 <= 32) c = 2;
+    else if (nt_max + 1 <= 64 && w == 4 && lds_bytes_for(w, r, 4, false) <= 160 * 1024) c = 4;
+    else b = 1;
+    const size_t lb = lds_bytes_for(w, r, c, b);
     if (lb > 160 * 1024) return SOSGPU_E_UNSUPPORTED;
+    if (nw) *nw = w;
     if (rtw) *rtw = r;
     if (ct) *ct = c;
     if (lds_bytes) *lds_bytes = lb;
@@ -634,35 +668,36 @@ int sos_os_variant(int n, int nt_max, int *rtw, int *ct, size_t *lds_bytes, int 
 size_t sos_os_scratch_doubles(int n, int lpb)
 {
     const int kh = sos_round_up(3 * n, 8);
-    return (size_t)lpb * (2 * kh) + (size_t)lpb * n + 7 * (size_t)lpb;
+    const int w = kh <= 128 ? 4 : 8, r = kh <= 64 ? 1 : 2;
+    return (size_t)lpb * (sos_fs(w, r) + sos_ns(w, r) + 7);
 }
 
-template <int RTWH, int CT, bool BIG, bool ZO>
+template <int NW, int RTWH, int CT, bool BIG, bool ZO>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
-    auto kern = k_sos_os<RTWH, CT, BIG, ZO>;
+    auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -2;
     const int grid = bn.nb;
-    kern<<<grid, 256, lds, st>>>(cx, bn);
+    kern<<<grid, 64 * NW, lds, st>>>(cx, bn);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st)
 {
-    int rtw, ct, big;
+    int nw, rtw, ct, big;
     size_t lds;
-    const int rc = sos_os_variant(cx.n, nt_max, &rtw, &ct, &lds, &big);
+    const int rc = sos_os_variant(cx.n, nt_max, &nw, &rtw, &ct, &lds, &big);
     if (rc) return rc;
-    if (cx.rtph != 4 * rtw) return SOSGPU_E_UNSUPPORTED;
+    if (cx.kh > sos_khm(nw, rtw) || cx.rtph * 16 < cx.kh) return SOSGPU_E_UNSUPPORTED;
     if (big && (!bn.scratch || bn.lpb < nt_max + 1)) return SOSGPU_E_UNSUPPORTED;
     const int zo = bn.jout != nullptr;
-#define V(R, C, B)                                                                        \
-    if (rtw == R && ct == C && big == B)                                                  \
-        return zo ? launch_variant<R, C, B, true>(cx, bn, lds, st) : launch_variant<R, C, B, false>(cx, bn, lds, st);
-    V(1, 2, 0) V(2, 2, 0) V(3, 2, 0) V(4, 2, 0)
-    V(1, 4, 0) V(2, 4, 0) V(3, 4, 0)
-    V(1, 2, 1) V(2, 2, 1) V(3, 2, 1) V(4, 2, 1)
+#define V(NWV, R, C, B)                                                                   \
+    if (nw == NWV && rtw == R && ct == C && big == B)                                     \
+        return zo ? launch_variant<NWV, R, C, B, true>(cx, bn, lds, st) : launch_variant<NWV, R, C, B, false>(cx, bn, lds, st);
+    V(4, 1, 2, 0) V(4, 2, 2, 0) V(8, 2, 2, 0)
+    V(4, 1, 4, 0) V(4, 2, 4, 0)
+    V(4, 1, 2, 1) V(4, 2, 2, 1) V(8, 2, 2, 1)
 #undef V
     return SOSGPU_E_UNSUPPORTED;
 }

@@ -68,6 +68,21 @@ def make_case(name):
     elif name == "aer_n9_nt600":          # CTE_OS_NT = 600 (SOS.h:202)
         ng, nt, os_nb, g, kabs = 8, 600, 16, 0.5, [1.0]
         kw = dict(ro=0.1)
+    elif name == "aer_n21":               # NW=4, one row tile per wave
+        ng, nt, os_nb, g, kabs = 20, 28, 40, 0.7, [0.0, 1.5]
+        kw = dict(ro=0.15)
+    elif name == "zout_n21_nt50":         # one row tile per wave, four column tiles
+        ng, nt, os_nb, g, kabs = 20, 50, 40, 0.7, [0.4]
+        kw = dict(ro=0.05, zout=4.0)
+    elif name == "aer_n49":               # N > 42: eight-wave workgroups
+        ng, nt, os_nb, g, kabs = 48, 26, 80, 0.75, [0.0, 2.0]
+        kw = dict(ro=0.1)
+    elif name == "fresnel_n80_nt24":      # CTE_OS_NBMU_MAX = 80 directions (SOS.h:471)
+        ng, nt, os_nb, g, kabs = 79, 24, 80, 0.8, [0.3]
+        kw = dict(ro=0.03, ifresnel=1, ind_surf=1.34)
+    elif name == "zout_n65_nt45":         # N > 42 with the field in the HBM scratch
+        ng, nt, os_nb, g, kabs = 64, 45, 64, 0.7, [0.6]
+        kw = dict(ro=0.2, zout=2.5)
     elif name.startswith("x_"):           # ad-hoc debugging case: x_<ng>_<nt>_<os_nb>_<g>_<zout or -1>
         f = name.split("_")
         ng, nt, os_nb, g, kabs = int(f[1]), int(f[2]), int(f[3]), float(f[4]), [0.0]
@@ -98,7 +113,8 @@ def make_case(name):
 
 ALL_CASES = ["rayleigh_n25", "aer_n41", "aer_n41_g09", "fresnel_n41", "nopolar_n41", "zout_n25_nt60",
              "brdf_n13", "brdf_zout_n13", "black_n9", "igmax_n9",
-             "rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600"]
+             "rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600",
+             "aer_n21", "zout_n21_nt50", "aer_n49", "fresnel_n80_nt24", "zout_n65_nt45"]
 
 
 def run_cpu(mod, case, b):

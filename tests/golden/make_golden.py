@@ -19,8 +19,8 @@ import cases  # noqa: E402
 from oracle import ref_ctypes as R  # noqa: E402
 
 
-def gen_sos_os():
-    for name in cases.ALL_CASES:
+def gen_sos_os(only=None):
+    for name in (only or cases.ALL_CASES):
         case = cases.make_case(name)
         d = dict(rmu=case["rmu"], ga=case["ga"], n0=case["n0"], os_nb=case["os_nb"], iborm=case["iborm"],
                  alpha=case["coefs"][0], beta=case["coefs"][1], gamma=case["coefs"][2], zeta=case["coefs"][3],
@@ -127,6 +127,9 @@ def gen_sos_proc():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                 # python make_golden.py <sos_os case> ...: only these SOS_OS fixtures
+        gen_sos_os(sys.argv[1:])
+        sys.exit(0)
     gen_sos_proc()
     gen_glitter()
     gen_trphi()
