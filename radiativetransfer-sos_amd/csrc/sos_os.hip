@@ -21,6 +21,7 @@
 //    tail, the Fourier accumulation and the Fourier stop are per-thread register state.
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
+#include <cstdlib>
 #include <type_traits>
 #include "sos_common.h"
 #include "kernels.h"
@@ -104,62 +105,81 @@ __device__ __forceinline__ double queue_term(double d, double g)
 //   acc[sr] += U (YDEL o (V^T X^sr))                                             (noyaux.hip k_pack_ray)
 // A wave works on NA (1 or 2) row tiles tile0, tile0 + NW of BOTH systems x CT column tiles; bx = its B-fragment
 // base (column lane&15, k-quad lane>>4) in the LDS field/staging buffer with level stride FS.
-template <int NA, int RTWH, int CT, int NW, int FS, int KHM>
+// Software pipeline: the A fragments (global/L2) and the raw B operands X+, X- (LDS) of k-pair m+1 are requested
+// before the 16+ MFMAs of k-pair m are issued (two register sets each, used alternately, no copies), so neither the
+// L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection rides in the same loop (RAY = half
+// system it acts on, -1 = none): 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
+template <int NA, int RAY, int RTWH, int CT, int NW, int FS, int KHM>
 __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
-                                            const double *__restrict__ vt, const double *__restrict__ uf, int ray_sys,
+                                            const double *__restrict__ vt, const double *__restrict__ uf,
                                             int ks2h, int rtph, const double *bx, const double *xdel,
                                             const double *ydel, int lane, int tile0)
 {
-    auto b_fragments = [&](v2d (&ba)[CT], v2d (&bb)[CT], int m) {
+    struct BRaw { v2d xp[CT], xm[CT]; };
+    auto load_b = [&](BRaw &b, int m) {
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
-            const v2d xp = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + 8 * m);
-            const v2d xm = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + KHM + 8 * m);
-            ba[ct] = xp + xm;
-            bb[ct] = xp - xm;
+            b.xp[ct] = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + 8 * m);
+            b.xm[ct] = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + KHM + 8 * m);
         }
     };
+    const v2d *vp = reinterpret_cast<const v2d *>(vt) + lane;
+    v4d pr[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) pr[ct] = (v4d){0., 0., 0., 0.};
     if (do_aer) {
         const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
         const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
         const v2d *ap = reinterpret_cast<const v2d *>(mp) + (size_t)tile0 * rts + lane;
-        // two register sets of A fragments used alternately (k-pair m from one set while m+1 loads into the other):
-        // no register-to-register copies in the loop
-        v2d a0[2][NA], a1[2][NA];
-        auto load_a = [&](v2d (&a)[2][NA], int m) {
+        struct AFrag { v2d a[2][NA]; v2d v; };
+        auto load_a = [&](AFrag &f, int m) {
 #pragma unroll
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                for (int rt = 0; rt < NA; rt++) a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
+                for (int rt = 0; rt < NA; rt++) f.a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
+            if (RAY >= 0) f.v = vp[(size_t)m * 64];
         };
-        auto mma = [&](const v2d (&a)[2][NA], int m) {
+        auto mma = [&](const AFrag &f, const BRaw &b) {
             v2d ba[CT], bb[CT];
-            b_fragments(ba, bb, m);
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
 #pragma unroll
             for (int rt = 0; rt < NA; rt++)
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
                 }
 #pragma unroll
             for (int rt = 0; rt < NA; rt++)
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
                 }
+            if (RAY >= 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    const v2d bq = RAY ? bb[ct] : ba[ct];
+                    pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v.x, bq.x, pr[ct], 0, 0, 0);
+                    pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v.y, bq.y, pr[ct], 0, 0, 0);
+                }
+            }
         };
-        load_a(a0, 0);
+        AFrag f0, f1;
+        BRaw b0, b1;
+        load_a(f0, 0);
+        load_b(b0, 0);
         int m = 0;
 #pragma unroll 1
         for (; m + 1 < ks2h; m += 2) {
-            load_a(a1, m + 1);
-            mma(a0, m);
-            if (m + 2 < ks2h) load_a(a0, m + 2);
-            mma(a1, m + 1);
+            load_a(f1, m + 1);
+            load_b(b1, m + 1);
+            mma(f0, b0);
+            if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
+            mma(f1, b1);
         }
-        if (m < ks2h) mma(a0, m);
+        if (m < ks2h) mma(f0, b0);
         // XDEL of the output level: every accumulator register of a lane belongs to one column
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
@@ -169,27 +189,32 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
                 for (int rt = 0; rt < NA; rt++) acc[sy][rt][ct] *= sc;
         }
-    }
-    if (ray_sys >= 0) {
-        // projections pr = V^T X^sr: one 16-row tile (rows 0..3 used) per column tile, every wave computes them itself
-        // (2 CT KS2H MFMAs instead of a second dense pass, and no cross-wave exchange)
-        const v2d *vp = reinterpret_cast<const v2d *>(vt) + lane;
-        v4d pr[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) pr[ct] = (v4d){0., 0., 0., 0.};
-#pragma unroll 1
-        for (int m = 0; m < ks2h; m++) {
-            const v2d a = vp[(size_t)m * 64];
-            v2d ba[CT], bb[CT];
-            b_fragments(ba, bb, m);
+    } else if (RAY >= 0) {
+        // molecular atmosphere: only the projections pr = V^T X^sr (one 16-row tile, rows 0..3 used, per column tile)
+        v2d v0 = vp[0], v1;
+        BRaw b0, b1;
+        load_b(b0, 0);
+        auto prj = [&](const v2d &v, const BRaw &b) {
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                const v2d b = ray_sys ? bb[ct] : ba[ct];
-                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, pr[ct], 0, 0, 0);
-                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, pr[ct], 0, 0, 0);
+                const v2d bq = RAY ? b.xp[ct] - b.xm[ct] : b.xp[ct] + b.xm[ct];
+                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, bq.x, pr[ct], 0, 0, 0);
+                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, bq.y, pr[ct], 0, 0, 0);
             }
+        };
+        int m = 0;
+#pragma unroll 1
+        for (; m + 1 < ks2h; m += 2) {
+            v1 = vp[(size_t)(m + 1) * 64];
+            load_b(b1, m + 1);
+            prj(v0, b0);
+            if (m + 2 < ks2h) { v0 = vp[(size_t)(m + 2) * 64]; load_b(b0, m + 2); }
+            prj(v1, b1);
         }
-        // register 0 of the result holds row (lane>>4) in 0..3, column lane&15: exactly the B-operand layout of one
+        if (m < ks2h) prj(v0, b0);
+    }
+    if (RAY >= 0) {
+        // register 0 of pr holds row (lane>>4) in 0..3, column lane&15: exactly the B-operand layout of one
         // K = 4 step, so the expansion U * (YDEL o pr) needs no data movement
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
@@ -197,8 +222,7 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 #pragma unroll
             for (int rt = 0; rt < NA; rt++) {
                 const double u = uf[(size_t)(tile0 + rt * NW) * 64 + lane];
-                if (ray_sys) acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[1][rt][ct], 0, 0, 0);
-                else acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[0][rt][ct], 0, 0, 0);
+                acc[RAY > 0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[RAY > 0][rt][ct], 0, 0, 0);
             }
         }
     }
@@ -210,21 +234,35 @@ __host__ __device__ constexpr int sos_khm(int nw, int rtwh) { return 16 * nw * r
 __host__ __device__ constexpr int sos_fs(int nw, int rtwh) { return 2 * sos_khm(nw, rtwh) + 2; }
 __host__ __device__ constexpr int sos_ns(int nw, int rtwh) { return (sos_khm(nw, rtwh) / 3 + 1) & ~1; }
 
-// One level of the formal solution (SOS_INTEGR_EPOPT, SOS_OS.F:2279-2354).  With t = exp(-dtau/|mu|) and the source
-// linear in tau on the layer, both directions reduce to the same three-term recurrence
-//     X_i = t X_n + p S_i + w S_n,   w = (1-t) |mu|/dtau - t,  p = (1-t) - w
+// Formal solution of one row (SOS_INTEGR_EPOPT, SOS_OS.F:2279-2354).  With t = exp(-dtau/|mu|) and the source linear
+// in tau on the layer, both directions reduce to the same three-term recurrence
+//     X_i = t X_n + (p S_i + w S_n),   w = (1-t) |mu|/dtau - t,  p = (1-t) - w
 // (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), algebraically the reference update
-// X t + (1-t)(a mu + b) -/+ a t dtau.  7 FP64 instructions per level, one of them on the dependent chain.
-#define SOS_LEVEL(SRC, DST, A, IDT)                                       \
-    {                                                                    \
-        const double a_ = (A), si_ = (SRC), r_ = mu * (IDT);             \
-        const double omt_ = 1.0 - a_;                                    \
-        const double w_ = omt_ * r_ - a_;                                \
-        const double pq_ = omt_ - w_;                                    \
-        z = z * a_ + (pq_ * si_ + w_ * sn);                              \
-        (DST) = z;                                                       \
-        sn = si_;                                                        \
+// X t + (1-t)(a mu + b) -/+ a t dtau.  A block of U levels is processed in three passes so that neither the LDS
+// round trip nor the FP64 latency sits between two levels: (1) all operands of the block are loaded (the stores of
+// the block come last, so the loads cannot be held back by possible aliasing), (2) the U independent coefficient /
+// source combinations run with full instruction-level parallelism, (3) only one FMA per level is on the dependent
+// chain.  DI = -1 sweeps from level nt down to 0 (up-going rows), DI = +1 from 0 to nt; all offsets are immediates.
+template <int DI, int U, int FS, int NS>
+__device__ __forceinline__ void scan_block(double *&q, const double *&qa, const double *&qd, double mu, double &z, double &sn)
+{
+    double av[U], sv[U], cv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { av[u] = qa[DI * u * NS]; cv[u] = qd[DI * u]; sv[u] = q[DI * (u + 1) * FS]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double omt = 1.0 - av[u];
+        const double w = omt * (mu * cv[u]) - av[u];
+        const double pq = omt - w;
+        cv[u] = pq * sv[u] + w * (u ? sv[u - 1] : sn);
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { z = z * av[u] + cv[u]; cv[u] = z; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[DI * (u + 1) * FS] = cv[u];
+    sn = sv[U - 1];
+    q += DI * U * FS; qa += DI * U * NS; qd += DI * U;
+}
 
 // NW   : waves per workgroup (4: N <= 42, 8: N <= 85); waves [0,NW/2) hold up-going rows, the rest down-going rows
 // RTWH : row tiles per wave and half system (tile = wave + rt*NW)
@@ -355,18 +393,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             double z = bcv;
             double sn = *q;                             // source at the level the ray comes from
             *q = z;
-            auto block = [&](auto cnt_tag) {
-                constexpr int U = decltype(cnt_tag)::value;
-#pragma unroll
-                for (int u = 0; u < U; ++u) SOS_LEVEL(q[DI * (u + 1) * FS], q[DI * (u + 1) * FS], qa[DI * u * NS], qd[DI * u])
-                q += DI * U * FS; qa += DI * U * NS; qd += DI * U;
-            };
             int k = 0;
 #pragma unroll 1
-            for (; k + 8 <= nt; k += 8) block(std::integral_constant<int, 8>());
-            if (nt & 4) block(std::integral_constant<int, 4>());
-            if (nt & 2) block(std::integral_constant<int, 2>());
-            if (nt & 1) block(std::integral_constant<int, 1>());
+            for (; k + 8 <= nt; k += 8) scan_block<DI, 8, FS, NS>(q, qa, qd, mu, z, sn);
+            if (nt & 4) scan_block<DI, 4, FS, NS>(q, qa, qd, mu, z, sn);
+            if (nt & 2) scan_block<DI, 2, FS, NS>(q, qa, qd, mu, z, sn);
+            if (nt & 1) scan_block<DI, 1, FS, NS>(q, qa, qd, mu, z, sn);
             xb = z;
         };
         auto scan_row = [&](double bcv) {
@@ -539,13 +571,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     const double *mpa = cx.mp_aer + (size_t)s * mper;
                     const double *vtp = cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128;
                     const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
-                    const int ray_sys = s <= 2 ? (s & 1) : -1;
-                    if (tile_b)
-                        gemm_source<RTWH, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, ray_sys, cx.ks2h, cx.rtph,
-                                                                 bx, xdel + l0, ydel + l0, lane, wv);
-                    else if (tile_a)
-                        gemm_source<1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, ray_sys, cx.ks2h, cx.rtph,
-                                                              bx, xdel + l0, ydel + l0, lane, wv);
+                    // RAY: half system the molecular operator acts on (A for even s, B for odd s), none for s > 2
+                    auto contract = [&](auto na_tag) {
+                        constexpr int NA = decltype(na_tag)::value;
+                        if (s > 2)
+                            gemm_source<NA, -1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,
+                                                                       xdel + l0, ydel + l0, lane, wv);
+                        else if (s & 1)
+                            gemm_source<NA, 1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,
+                                                                      xdel + l0, ydel + l0, lane, wv);
+                        else
+                            gemm_source<NA, 0, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,
+                                                                      xdel + l0, ydel + l0, lane, wv);
+                    };
+                    if (tile_b) contract(std::integral_constant<int, RTWH>());
+                    else if (tile_a) contract(std::integral_constant<int, 1>());
                     __syncthreads();
                     PH(2);
                     // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
@@ -676,6 +716,9 @@ template <int NW, int RTWH, int CT, bool BIG, bool ZO>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
     auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO>;
+#ifdef SOS_PROFILE_PHASES
+    if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
+#endif
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -2;
     const int grid = bn.nb;
