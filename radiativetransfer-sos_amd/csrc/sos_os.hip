@@ -22,14 +22,17 @@
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
 #include <cstdlib>
+#include <cstdlib>
 #include <type_traits>
 #include "sos_common.h"
 #include "kernels.h"
 
 #define SOSGPU_E_UNSUPPORTED -3
 #ifdef SOS_PROFILE_PHASES
-#define PH_T0() unsigned long long ph_t = __builtin_amdgcn_s_memtime()
-#define PH(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
+// s_memrealtime: constant 100 MHz counter (s_memtime is NOT wall-clock on gfx950 when waves share a SIMD: it advances
+// at 1/k of the shader clock with k MFMA-streaming waves per SIMD -- scripts/ubench_mfma_peak.hip)
+#define PH_T0() unsigned long long ph_t = __builtin_amdgcn_s_memrealtime()
+#define PH(k) do { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
 #else
 #define PH_T0() do {} while (0)
 #define PH(k) do {} while (0)
@@ -716,6 +719,9 @@ template <int NW, int RTWH, int CT, bool BIG, bool ZO>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
     auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO>;
+#ifdef SOS_PROFILE_PHASES
+    if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
+#endif
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif

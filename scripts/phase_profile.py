@@ -22,4 +22,4 @@ tot = p.sum()
 steps = (out["iglast"].cpu().numpy().clip(min=1) - 1).sum()
 print("bins", nb, "ig steps", steps, "kernel ms", cx.last_solve_ms())
 for k, nme in enumerate(names):
-    print("%-14s %6.2f %%   %10.0f cycles per ig-step" % (nme, 100 * p[:, k].sum() / tot, p[:, k].sum() / steps))
+    print("%-14s %6.2f %%   %8.3f us per ig-step (100 MHz s_memrealtime)" % (nme, 100 * p[:, k].sum() / tot, p[:, k].sum() / steps / 100.0))
