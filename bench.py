@@ -23,7 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 32 flop/clk/SIMD * 1024 SIMD * 2.4 GHz
+FP64_PEAK_TFLOPS = 78.6   # MI355X dense FP64 MFMA peak (MI355X_MICROARCH.md); scripts/ubench_mfma_peak.hip measures 78.1 on the box
 
 
 def build_workload(S, nb, nt, seed, g):
@@ -143,18 +143,32 @@ def main():
         cx.solve(bins, out)
         durs.append(cx.last_solve_ms())
     kern_ms = float(np.mean(durs))
-    flops = cx.solve_flops(bins, out)
-    achieved = flops / (kern_ms * 1e-3) / 1e12
+    flops_ref, flops_exe = cx.solve_flops(bins, out)
+    achieved = flops_exe / (kern_ms * 1e-3) / 1e12
+    # HBM traffic of one launch: rocprofv3 PMC passes of this same command, summarised (with the gfx950 corrections
+    # of MI355X_MICROARCH.md) by scripts/summarize_profiles.py into profiles/; null when the workload differs
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+            pm = json.load(f)
+        if pm.get("bins_per_gpu") == args.bins and pm.get("nt") == args.nt:
+            traffic = pm["k_sos_os_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     res = dict(metric="CKD spectral bins/sec (full Stokes I,Q,U, TOA+surface)", value=nb_tot * args.steps / dt,
                unit="bins/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload="single-wavelength aerosol+Rayleigh, 40 Gauss angles (N=41), NT=%d layers, OS_NB=80, "
                                     "Lambertian rho=0.1, HG g=%.2f, %d CKD bins/GPU/step" % (args.nt, args.g, args.bins),
-                           bins_per_gpu=args.bins, nt=args.nt, n_dirs=41, os_nb=80, parallelism="bins sharded x%d" % world),
+                           bins_per_gpu=args.bins, nt=args.nt, n_dirs=41, os_nb=80, parallelism="bins sharded x%d" % world,
+                           bin_order="generation" if args.no_sort else "cost-sorted"),
                roofline=dict(bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                             frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
-                             kernel="k_sos_os<4,2>", kernel_ms=kern_ms, flops_per_launch=flops))
+                             frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
+                             kernel="k_sos_os<4,2,2,false,false>", kernel_ms=kern_ms, flops_per_launch=flops_exe,
+                             flops_counted="parity (two 3N x 3N half systems) + rank-4 molecular form + formal solution, unpadded",
+                             reference_algorithm_flops_per_launch=flops_ref,
+                             reference_algorithm_tflops=flops_ref / (kern_ms * 1e-3) / 1e12))
     if rank == 0:
         nord = out["norders"].cpu().numpy()
         res["config"]["mean_fourier_orders"] = float(nord.mean())

@@ -143,9 +143,12 @@ int  sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double tau, doubl
 /* Scratch requirements (bytes) of the context on its device, for memory planning. */
 size_t sosgpu_ctx_bytes(const sosgpu_ctx *cx);
 
-/* Algorithmic flop count of the last sosgpu_os_solve (per (bin, order, scattering
- * order >= 2) step 2*(6N)^2*(NT+1) [+ the Rayleigh operator for s<=2] + 12*6N*NT), computed on the
- * host from d_nt/d_norders/d_iglast after a synchronise.  Used by bench.py for roofline.achieved. */
+/* Floating-point work of the last solve, computed on the host from d_nt/d_norders/d_iglast after a synchronise
+ * (used by bench.py for the roofline).  flops_out[0] = SURVEY 8d count of the reference algorithm: every computed
+ * scattering order >= 2 costs 2*(6N)^2*(NT+1) [+ 2*3*6N*(NT+1)*3 for the molecular operator, s <= 2] + 12*6N*NT.
+ * flops_out[1] = the same steps in the form this library executes: two 3N x 3N half systems
+ * 2*2*(3N)^2*(NT+1), the molecular operator in rank-4 form 2*2*4*3N*(NT+1) for s <= 2, and 10 flops per row and
+ * layer of formal solution (6N*NT*10); padding to MFMA tiles is not counted. */
 int  sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, const int32_t *d_norders,
                      const int32_t *d_iglast, double *flops_out);
 

@@ -286,19 +286,22 @@ extern "C" int sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, cons
     HIPCHK(hipMemcpy(nt.data(), d_nt, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(no.data(), d_norders, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ig.data(), d_iglast, (size_t)nb * S1 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    const double r6 = 6.0 * cx->d.n;
-    double tot = 0.;
+    const double r6 = 6.0 * cx->d.n, r3 = 3.0 * cx->d.n;
+    double tot = 0., exe = 0.;
     for (int b = 0; b < nb; b++) {
         const double L = nt[b] + 1.0;
         for (int s = 0; s < no[b]; s++) {
             const int steps = ig[(size_t)b * S1 + s] - 1;    // scattering orders >= 2 actually computed
             if (steps <= 0) continue;
             double w = 2. * r6 * r6 * L + 12. * r6 * nt[b];  // SURVEY 8d W_step
-            if (s <= 2) w += 2. * 3. * r6 * L * 3.;
+            double e = 2. * 2. * r3 * r3 * L + 10. * r6 * nt[b];
+            if (s <= 2) { w += 2. * 3. * r6 * L * 3.; e += 2. * 2. * 4. * r3 * L; }
             tot += steps * w;
+            exe += steps * e;
         }
     }
-    *flops_out = tot;
+    flops_out[0] = tot;
+    flops_out[1] = exe;
     return SOSGPU_OK;
 }
 

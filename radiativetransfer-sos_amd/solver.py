@@ -158,11 +158,13 @@ class SosContext:
         return ms.value
 
     def solve_flops(self, bins, out):
-        fl = C.c_double(0)
+        """(reference-algorithm flops, flops of the parity / rank-4 form executed) of the last solve; see
+        sosgpu_os_flops in include/sosgpu.h."""
+        fl = (C.c_double * 2)(0.0, 0.0)
         torch.cuda.synchronize(self.device)
         capi.check(capi.lib().sosgpu_os_flops(self._h, bins["nb"], _ptr(bins["nt"]), _ptr(out["norders"]),
-                                              _ptr(out["iglast"]), C.byref(fl)), "sosgpu_os_flops")
-        return fl.value
+                                              _ptr(out["iglast"]), fl), "sosgpu_os_flops")
+        return fl[0], fl[1]
 
     def aggregate(self, out, aik, seg=None, scal=None):
         """SOS_AGGREGATE over segments of bins (default: all bins = one wavelength).  Returns
