@@ -107,6 +107,10 @@ def test_full_size_properties(gpu_pkg):
     o3 = cx.solve(cx.upload_bins(h[perm], x[perm], y[perm]))
     torch.cuda.synchronize()
     assert torch.equal(o3["rec"], r1[torch.from_numpy(perm).to(r1.device)])
+    bs = cx.upload_bins(h, x, y, order="cost")                  # cost-sorted upload returns its permutation
+    o4 = cx.solve(bs)
+    torch.cuda.synchronize()
+    assert torch.equal(o4["rec"], r1[torch.from_numpy(bs["perm"]).to(r1.device)])
     # linearity / sharding of the aggregate
     rec_all, sc_all = cx.aggregate(o2, aik)
     direct = (torch.from_numpy(aik).to(r1.device)[:, None, None, None] * r1).sum(0)
