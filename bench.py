@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--bins", type=int, default=4096, help="CKD bins per GPU per step")
     ap.add_argument("--nt", type=int, default=30)
     ap.add_argument("--g", type=float, default=0.75)
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=224, help="bins timed on the CPU baseline (about 15 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-sort", action="store_true", help="keep the bins in generation order (default: cost-sorted upload)")
     args = ap.parse_args()
