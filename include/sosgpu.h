@@ -156,6 +156,24 @@ int  sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, const int32_t 
  * Synchronises that stream. */
 int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
 
+/* Per-bin atmospheric profiles on the device: SOS_PROFILE for IPROFIL = 1 (src/SOS_PROFIL.F:224-1170) with SOS_DISC
+ * (:1210-1332), the PROFIL-file round trip (formats F10.5 / E15.8, SOS_PROFIL.F:1084,1150 -> SOS.F:515,692), the truncation
+ * rescale and IBORM of SOS (src/SOS.F:521-550), TAUOUT / TTOT (SOS.F:567-589) and the output level of SOS_OS.F:1514-1520,
+ * for nb CKD bins at once.  Replaces the per-bin calls `CALL SOS_PROFILE` (SOS_PROC.F:3509) + the read in `SOS`.
+ *   tr, hr, ta, ha      Rayleigh / aerosol optical thickness and scale heights of the wavelength
+ *   d_tabs[nb][nblev]   cumulative gas absorption optical depth of every bin on the altitude grid d_altabs[nblev]
+ *                       (descending, ground last; CTE_ABS_NBLEV = 50 in the reference); NULL = no gas (ABSPROFIL = 7)
+ *   a_tronc, piz, piztr truncation coefficient and single-scattering albedos of SOS.F:523-541;  zout: -1 = TOA/ground
+ * Outputs (device): d_prof[nb][3][lp] (H, XDEL, YDEL as sosgpu_os_solve takes them), d_nt[nb] (-1: the profile needs
+ * more than CTE_OS_NT = 600 levels or lp is too small -- the reference's IER = -1), d_iborm[nb], d_zprof[nb][lp],
+ * d_jout[nb] / d_zz[nb] (NULL when zout = -1), d_scal[nb][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT} (the layout
+ * sosgpu_aggregate takes).  IPROFIL = 2 (aerosol layer between two altitudes) is not implemented. */
+int  sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, double ha, int absprofil,
+                    int nblev, const double *d_altabs, const double *d_tabs,
+                    double a_tronc, double piz, double piztr, double zout, int lp,
+                    double *d_prof, int32_t *d_nt, int32_t *d_iborm, double *d_zprof,
+                    int32_t *d_jout, double *d_zz, double *d_scal, void *stream);
+
 /* Diagnostic hook: hand the context a device buffer [nb][8] of uint64 that builds compiled with
  * -DSOS_PROFILE_PHASES fill with per-phase cycle sums of the solver kernel (0 order-1 fill, 1 formal solution,
  * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.

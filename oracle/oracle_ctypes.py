@@ -162,3 +162,23 @@ def polar(xi, xq, xu):
     a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
     lib().sos_oracle_polar(C.c_double(xi), C.c_double(xq), C.c_double(xu), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def sos_profile(tr, hr, ta, ha, altabs=None, tabs=None, absprofil=1):
+    """SOS_PROFILE for IPROFIL=1 (SOS_PROFIL.F:224) as read back from the PROFIL file: returns dict(ier, nt, zprof, h,
+    xdel (=PCAER), ydel (=PCMOL)).  tabs=None or all-zero last level: no gas absorption."""
+    n = 601
+    z, h, pa, pm = (np.zeros(n) for _ in range(4))
+    nt = C.c_int(0)
+    if tabs is None:
+        p_alt, p_tab, absprofil = None, None, 7
+    else:
+        a_alt = np.ascontiguousarray(altabs, dtype=np.float64); a_tab = np.ascontiguousarray(tabs, dtype=np.float64)
+        assert a_alt.shape == (50,) and a_tab.shape == (50,)
+        p_alt, p_tab = a_alt.ctypes.data_as(C.c_void_p), a_tab.ctypes.data_as(C.c_void_p)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().sos_profile_oracle.restype = C.c_int
+    ier = lib().sos_profile_oracle(C.c_double(tr), C.c_double(hr), C.c_double(ta), C.c_double(ha), C.c_int(absprofil),
+                                   p_alt, p_tab, C.byref(nt), vp(z), vp(h), vp(pa), vp(pm))
+    k = nt.value + 1
+    return dict(ier=ier, nt=nt.value, zprof=z[:k].copy(), h=h[:k].copy(), xdel=pa[:k].copy(), ydel=pm[:k].copy())

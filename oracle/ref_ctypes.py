@@ -373,3 +373,34 @@ def sos_proc(kwargs_in_order):
 
     _big_stack_call(call)
     return (lum_nbmu.value, ind_angout, phi, theta, *[np.ascontiguousarray(t) for t in tabs], *[s.value for s in scal])
+
+
+def sos_profile(tr, hr, ta, ha, altabs=None, tabs=None, absprofil=1):
+    """Reference SOS_PROFILE (SOS_PROFIL.F:224) for IPROFIL=1; the PROFIL file it writes is parsed with the read format of
+    SOS.F:515,692 (`2X,I5,F10.5,3(E15.8)`).  Same return as oracle_ctypes.sos_profile."""
+    tmp = tempfile.mkdtemp(prefix="sosref_")
+    try:
+        fic = os.path.join(tmp, "PROFIL")
+        if tabs is None:
+            a_alt = np.linspace(120.0, 0.0, 50); a_tab = np.zeros(50); absprofil = 7
+        else:
+            a_alt = np.ascontiguousarray(altabs, dtype=np.float64); a_tab = np.ascontiguousarray(tabs, dtype=np.float64)
+        nt, ier = C.c_int32(0), C.c_int32(0)
+        d = lambda v: C.byref(C.c_double(v))
+
+        def call():
+            lib().sos_profile_(C.byref(C.c_int16(1)), d(tr), d(hr), d(ta), d(ha), d(0.0), d(0.0),
+                               C.byref(C.c_int16(absprofil)), _p(a_alt), _p(a_tab), C.byref(C.c_int32(0)),
+                               C.byref(C.c_int32(99)), _fstr(fic), C.byref(nt), C.byref(ier), C.c_size_t(LENFIC2))
+
+        _big_stack_call(call)
+        if ier.value != 0:
+            return dict(ier=ier.value, nt=0, zprof=np.zeros(0), h=np.zeros(0), xdel=np.zeros(0), ydel=np.zeros(0))
+        rows = []
+        for line in open(fic):
+            rows.append((float(line[7:17]), float(line[17:32]), float(line[32:47]), float(line[47:62])))
+        a = np.array(rows)
+        assert len(a) == nt.value + 1
+        return dict(ier=0, nt=nt.value, zprof=a[:, 0].copy(), h=a[:, 1].copy(), xdel=a[:, 2].copy(), ydel=a[:, 3].copy())
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

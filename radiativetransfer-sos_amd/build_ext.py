@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libsosgpu.so")
-SOURCES = ["api.hip", "noyaux.hip", "sos_os.hip", "aggregate.hip", "glitter.hip", "trphi.hip"]
+SOURCES = ["api.hip", "noyaux.hip", "sos_os.hip", "aggregate.hip", "glitter.hip", "trphi.hip", "profile.hip"]
 
 
 def needs_build():

@@ -15,7 +15,7 @@ EXPORTS = [
     "sosgpu_strerror", "sosgpu_last_hip_error", "sosgpu_device_count", "sosgpu_version",
     "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
-    "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
+    "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
     "sosgpu_debug_phase_buffer",
 ]
 
@@ -68,6 +68,9 @@ def lib():
         L.sosgpu_aggregate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sosgpu_ctx_bytes.restype = C.c_size_t
         L.sosgpu_ctx_bytes.argtypes = [vp]
+        L.sosgpu_profile.restype = i32
+        L.sosgpu_profile.argtypes = [vp, i32, dbl, dbl, dbl, dbl, i32, i32, vp, vp, dbl, dbl, dbl, dbl, i32,
+                                     vp, vp, vp, vp, vp, vp, vp, vp]
         L.sosgpu_os_flops.restype = i32
         L.sosgpu_os_flops.argtypes = [vp, i32, vp, vp, vp, C.POINTER(dbl)]
         L.sosgpu_last_solve_ms.restype = i32

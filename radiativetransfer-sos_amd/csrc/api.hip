@@ -33,6 +33,7 @@ struct sosgpu_ctx {
     unsigned long long *phase;   // diagnostic phase-cycle buffer (sosgpu_debug_phase_buffer), else null
     double *agg_partial;    // chunk partials of the large-batch aggregate
     double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
+    double *prof_ng;        // [4][608] no-gas profile of the wavelength (sosgpu_profile)
     size_t scratch_doubles;
 };
 
@@ -94,6 +95,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->scratch_doubles = 0;
     cx->phase = nullptr;
     cx->agg_partial = nullptr;
+    cx->prof_ng = nullptr;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -174,6 +176,7 @@ extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
     hipSetDevice(cx->device);
     for (void *p : cx->allocs) hipFree(p);
     if (cx->scratch) hipFree(cx->scratch);
+    if (cx->prof_ng) hipFree(cx->prof_ng);
     if (cx->ev0) hipEventDestroy(cx->ev0);
     if (cx->ev1) hipEventDestroy(cx->ev1);
     delete cx;
@@ -455,6 +458,102 @@ extern "C" int sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double 
     HIPCHK(hipSetDevice(cx->device));
     launch_trphi(cx->d, nf, d_rec, tau, tauout, nphi, d_phi, igli, sigma2_of_wind(wind), cx->ind_surf, d_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SOS_PROFILE on the device.  The no-gas profile (SOS_PROFIL.F:349-489) is the same for every bin of a wavelength:
+// it is computed here on the host (O(NT * 25) exp, ~0.1 ms) and shared; the per-bin gas step runs in profile.hip.
+// ---------------------------------------------------------------------------------------------
+namespace {
+const int kOsNt = 600, kOsNtMin = 100;
+const double kTcouche = (double)0.005f, kTFirst = (double)0.0002f, kDeltaZ = (double)0.05f, kToa = 120.0;
+
+double disc_nogas(double dt, double ta, double ha, double tr, double hr, double tim1, double zmax_init)
+{
+    const double ti = tim1 + dt;                       // SOS_DISC with TG_ZLIM = 0 (SOS_PROFIL.F:1276-1325)
+    double zmax = zmax_init, zmin = 0., zmoy = 0.;
+    for (int guard = 0; guard < 4096; guard++) {
+        zmoy = (zmax + zmin) / 2.;
+        const double tz = ta * exp(-zmoy / ha) + tr * exp(-zmoy / hr) + 0.0;
+        if (fabs(ti - tz) < (double).000001f || zmoy == 0.0) break;
+        if ((ti - tz) < 0.0) zmin = zmoy; else zmax = zmoy;
+    }
+    return zmoy;
+}
+
+// returns NT_NG or -1; arrays z, h, pca, pcm of kOsNt + 1
+int profile_nogas_host(double tr, double hr, double ta, double ha, double *z, double *h, double *pca, double *pcm)
+{
+    int nt;
+    double t_first, t_layer;
+    const double ttot = tr + ta;
+    if ((ttot / kOsNtMin) <= kTFirst) { nt = kOsNtMin; t_layer = ttot / nt; t_first = t_layer; }
+    else if ((ttot / kOsNtMin) < kTcouche) { nt = kOsNtMin + 1; t_first = kTFirst; t_layer = (ttot - t_first) / kOsNtMin; }
+    else { t_first = kTFirst; nt = (int)((ttot - t_first) / kTcouche); t_layer = (ttot - t_first) / nt; nt = nt + 1; }
+    if (nt > kOsNt || !(ttot > 0.)) return -1;
+    std::vector<double> hmol(nt + 1), haer(nt + 1);
+    if (ta == 0.0) {
+        hmol[0] = 0.; hmol[1] = t_first;
+        for (int i = 2; i <= nt; i++) hmol[i] = (i - 1) * t_layer + t_first;
+        for (int i = 0; i <= nt; i++) { pcm[i] = 1.; pca[i] = 0.; haer[i] = 0.; }
+        z[0] = kToa;
+        for (int i = 1; i <= nt; i++) z[i] = hr * log(tr / hmol[i]);
+    } else {
+        z[0] = kToa; hmol[0] = 0.; haer[0] = 0.;
+        double dtau = 0., zz = kToa;
+        while (dtau < t_first) { zz = zz - kDeltaZ; dtau = tr * exp(-zz / hr) + ta * exp(-zz / ha); }
+        z[1] = zz;
+        double vr = tr * exp(-zz / hr), va = ta * exp(-zz / ha);
+        hmol[1] = vr; haer[1] = va;
+        pcm[1] = vr / dtau; pca[1] = va / dtau;
+        pcm[0] = pcm[1]; pca[0] = pca[1];
+        double hprev = dtau;
+        for (int i = 2; i <= nt - 1; i++) {
+            zz = disc_nogas(t_layer, ta, ha, tr, hr, hprev, z[1]);
+            z[i] = zz;
+            vr = tr * exp(-zz / hr); va = ta * exp(-zz / ha);
+            hmol[i] = vr; haer[i] = va; hprev = vr + va;
+            vr = vr - hmol[i - 1]; va = va - haer[i - 1];
+            pcm[i] = vr / (vr + va); pca[i] = va / (vr + va);
+        }
+        z[nt] = 0.; hmol[nt] = tr; haer[nt] = ta;
+        vr = tr - hmol[nt - 1]; va = ta - haer[nt - 1];
+        pcm[nt] = vr / (vr + va); pca[nt] = va / (vr + va);
+    }
+    for (int i = 0; i <= nt; i++) h[i] = hmol[i] + haer[i];
+    return nt;
+}
+}  // namespace
+
+extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, double ha, int absprofil,
+                              int nblev, const double *d_altabs, const double *d_tabs,
+                              double a_tronc, double piz, double piztr, double zout, int lp,
+                              double *d_prof, int32_t *d_nt, int32_t *d_iborm, double *d_zprof,
+                              int32_t *d_jout, double *d_zz, double *d_scal, void *stream)
+{
+    if (!cx || nb < 1 || lp < 2 || !d_prof || !d_nt || !d_iborm || !d_zprof || !d_scal) return SOSGPU_E_ARG;
+    if ((d_jout == nullptr) != (d_zz == nullptr)) return SOSGPU_E_ARG;
+    if (d_tabs && (!d_altabs || nblev < 2)) return SOSGPU_E_ARG;
+    if (!(hr > 0.) || !(ha > 0.) || tr < 0. || ta < 0.) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(cx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int NG = 608;
+    std::vector<double> ng((size_t)4 * NG, 0.);
+    const int nt_ng = profile_nogas_host(tr, hr, ta, ha, &ng[0], &ng[NG], &ng[2 * NG], &ng[3 * NG]);
+    if (nt_ng < 0) return SOSGPU_E_UNSUPPORTED;        // more than CTE_OS_NT levels (IER = -1 in the reference)
+    if (lp <= nt_ng) return SOSGPU_E_ARG;
+    if (!cx->prof_ng) HIPCHK(hipMalloc((void **)&cx->prof_ng, (size_t)4 * NG * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(cx->prof_ng, ng.data(), (size_t)4 * NG * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                 // ng is a stack-lifetime host buffer
+    ProfileArgs a;
+    a.nb = nb; a.lp = lp; a.nblev = nblev; a.absprofil = d_tabs ? absprofil : 7; a.smax = cx->d.smax; a.nt_ng = nt_ng;
+    a.tr = tr; a.hr = hr; a.ta = ta; a.ha = ha; a.a_tronc = a_tronc; a.piz = piz; a.piztr = piztr; a.zout = zout;
+    a.altabs = d_altabs; a.tabs = d_tabs;
+    a.z_ng = cx->prof_ng; a.h_ng = cx->prof_ng + NG; a.pca_ng = cx->prof_ng + 2 * NG; a.pcm_ng = cx->prof_ng + 3 * NG;
+    a.prof = d_prof; a.zprof = d_zprof; a.zz = d_zz; a.scal = d_scal; a.nt = d_nt; a.iborm = d_iborm; a.jout = d_jout;
+    launch_profile(a, st);
+    if (hipGetLastError() != hipSuccess) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
     return SOSGPU_OK;
 }
 

@@ -20,3 +20,14 @@ void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns,
                     int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st);
 void launch_trphi(const SosDev &cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
                   const double *d_phi, int igli, double sigma2, double ind_surf, double *d_out, hipStream_t st);
+
+// Per-bin profile discretisation (profile.hip).  *_ng: the no-gas profile of the wavelength (host-computed, device copy).
+struct ProfileArgs {
+    int nb, lp, nblev, absprofil, smax, nt_ng;
+    double tr, hr, ta, ha, a_tronc, piz, piztr, zout;
+    const double *altabs, *tabs;                 // [nblev], [nb][nblev] or null
+    const double *z_ng, *h_ng, *pca_ng, *pcm_ng;  // [nt_ng+1]
+    double *prof, *zprof, *zz, *scal;
+    int32_t *nt, *iborm, *jout;
+};
+void launch_profile(const ProfileArgs &a, hipStream_t st);

@@ -1,0 +1,293 @@
+// csrc/profile.hip -- per-bin atmospheric profile discretisation on the device (gfx950).
+//
+// Replaces, for every CKD bin of a wavelength at once, the step immediately before the solver:
+//   SOS_PROFILE (IPROFIL = 1)  src/SOS_PROFIL.F:224-1170   gas step :509-795 (level placement by optical-depth steps,
+//                                                            forced levels of the no-gas profile, limit layer for
+//                                                            strong absorption), PROFIL file formats :1084,1150
+//   SOS_DISC                   src/SOS_PROFIL.F:1210-1332  bisection on altitude
+//   SOS (wrapper)              src/SOS.F:511-550           read-back of the PROFIL file, truncation rescale, IBORM
+//                              src/SOS.F:567-589           TAUOUT / TTOT_TRONC; output level of SOS_OS.F:1514-1520
+// The reference writes one PROFIL text file per bin and reads it back; here the profile goes straight into the
+// device layout of sosgpu_os_solve and the text round trip (F10.5 / E15.8) is applied in registers, exactly.
+//
+// Work split: the no-gas profile (SOS_PROFIL.F:349-489) depends only on (TR,HR,TA,HA) -- identical for all bins of a
+// wavelength -- and is computed once on the host (api.hip); the gas step depends on the bin's absorption profile and
+// runs one thread per bin (the level loop is a serial recurrence: each level starts from the optical depth the
+// previous bisection actually reached).  Latency/transcendental-bound: ~NT * 25 bisection steps * 2 exp per bin, no
+// HBM traffic to speak of (50 doubles in, 4 * (NT+1) doubles out per bin).
+#include "sos_common.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                   1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// round(x * p) to the nearest integer (ties to even) where p is an exact power of ten: the product is formed exactly as
+// hi + lo (one FMA), so the decision never sees the rounding error of the multiplication
+__device__ __forceinline__ double round_scaled(double x, double p)
+{
+    const double hi = x * p;
+    const double lo = __builtin_fma(x, p, -hi);
+    double r = rint(hi);
+    const double d = (hi - r) + lo;                  // exact: |hi - r| <= 0.5, lo tiny
+    if (d > 0.5 || (d == 0.5 && fmod(r, 2.0) != 0.0)) r += 1.0;
+    else if (d < -0.5 || (d == -0.5 && fmod(r, 2.0) != 0.0)) r -= 1.0;
+    return r;
+}
+
+// value read back from a Fortran E15.8 field: 8 significant decimal digits, correctly rounded both ways
+// (decimal -> binary is r / 10^m with r < 2^27 and 10^m exact: one correctly rounded division)
+__device__ double rt_e15_8(double v)
+{
+    if (v == 0.0 || !isfinite(v)) return v;
+    const double av = fabs(v);
+    int e = (int)floor(log10(av));
+    // fix the estimate with exact comparisons where the powers are exact
+    if (e >= 0 && e < 22) { if (av >= P10[e + 1]) e++; else if (av < P10[e]) e--; }
+    else if (e < 0 && e >= -22) { if (av * P10[-e] < 1.0) e--; else if (e < -1 && av * P10[-e - 1] >= 1.0) e++; }
+    const int m = 7 - e;                             // scale so that the integer has 8 digits
+    double r;
+    if (m >= 0 && m <= 22) {
+        r = round_scaled(av, P10[m]);
+        if (r >= 1e8) return copysign(r / P10[m], v);            // carried into the next decade: same value
+        if (r < 1e7) {                                          // estimate one too high (only at exact powers of ten)
+            r = round_scaled(av, P10[m] * 10.0);
+            return copysign(r / (P10[m] * 10.0), v);
+        }
+        return copysign(r / P10[m], v);
+    }
+    if (m < 0) {                                     // |v| >= 1e8: divide
+        r = rint(av / P10[-m]);
+        return copysign(r * P10[-m], v);
+    }
+    // |v| < 1e-15: 10^m is not exact any more; these are fractions of 1e-15 of a layer, far below the parity bar
+    const double p = P10[22] * pow(10.0, (double)(m - 22));
+    r = rint(av * p);
+    return copysign(r / p, v);
+}
+
+__device__ __forceinline__ double rt_f10_5(double v) { return copysign(round_scaled(fabs(v), 1e5) / 1e5, v); }
+
+struct GasProf {
+    const double *alt, *tab;
+    int n;
+    // linear interpolation of the absorption optical depth at altitude z, clamped above the profile top
+    // (SOS_PROFIL.F:694-705; `outside` selects the two conventions the reference uses above ALTABS(1))
+    __device__ __forceinline__ int seg(double z) const
+    {
+        int j = 2;
+        while (z < alt[j - 1]) j++;
+        return j;
+    }
+};
+
+// SOS_DISC (SOS_PROFIL.F:1260-1325)
+__device__ double disc(double dt, double ta, double ha, double tr, double hr, const GasProf &g, double tim1,
+                       double zmax_init, double tg_zlim, double zlim)
+{
+    const double ti = tim1 + dt;
+    double zmax = zmax_init, zmin = zlim, zmoy;
+    for (int guard = 0; guard < 4096; guard++) {
+        double tg;
+        zmoy = (zmax + zmin) / 2.;
+        if (tg_zlim > 0.0) {
+            const int j = g.seg(zmoy);
+            double zz;
+            if (zmoy > g.alt[0]) zz = 0;
+            else zz = (zmoy - g.alt[j - 2]) / (g.alt[j - 1] - g.alt[j - 2]);
+            tg = (1 - zz) * g.tab[j - 2] + zz * g.tab[j - 1];
+        } else tg = 0.0;
+        const double tzmoy = ta * exp(-zmoy / ha) + tr * exp(-zmoy / hr) + tg;
+        const double xd = fabs(ti - tzmoy);
+        if (xd < (double).000001f) break;
+        if (zmoy == 0.0) break;
+        if ((ti - tzmoy) < 0.0) zmin = zmoy; else zmax = zmoy;
+    }
+    return zmoy;
+}
+
+}  // namespace
+
+// One thread per bin.  prof[b][3][lp] <- H, XDEL, YDEL (after the rescale), zprof[b][lp], nt, iborm, jout, zz,
+// scal[b][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT}; nt[b] = -1 flags a profile that does not fit (IER of the reference).
+__global__ __launch_bounds__(64) void k_profile(ProfileArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.nb) return;
+    const double TCOUCHE = (double)0.005f, T_FIRST = (double)0.0002f, DELTA_Z = (double)0.05f, DZ = (double)0.001f;
+    const double TAUABS_MAX = 1.5, TOA = 120.0;
+    const int OS_NT = 600, OS_NT_MIN = 100;
+    const double tr = a.tr, hr = a.hr, ta = a.ta, ha = a.ha;
+    double *H = a.prof + (size_t)b * 3 * a.lp, *XD = H + a.lp, *YD = XD + a.lp;
+    double *Z = a.zprof + (size_t)b * a.lp;
+    GasProf g;
+    g.alt = a.altabs; g.n = a.nblev;
+    g.tab = a.tabs ? a.tabs + (size_t)b * a.nblev : nullptr;
+    const double tgtot = g.tab ? g.tab[a.nblev - 1] : 0.0;
+    int nt;
+    bool bad = a.nt_ng < 1 || a.nt_ng > OS_NT || a.nt_ng >= a.lp;
+
+    if (bad) {
+        nt = 0;
+    } else if (a.absprofil == 7 || tgtot == 0.0) {                    // SOS_PROFIL.F:492-508
+        nt = a.nt_ng;
+        for (int i = 0; i <= nt; i++) { Z[i] = a.z_ng[i]; H[i] = a.h_ng[i]; XD[i] = a.pca_ng[i]; YD[i] = a.pcm_ng[i]; }
+    } else {
+        // ---- profile with gas absorption (SOS_PROFIL.F:509-795); Hmol/Haer/Habs of the previous level in registers
+        const bool strong = tgtot > TAUABS_MAX;
+        double t_first, t_layer, zlim, tg_zlim, ttot_zlim;
+        const double ttot = tr + ta + tgtot;
+        if (strong) {
+            int i = 1;
+            while (g.tab[i - 1] < TAUABS_MAX) i++;
+            const double alin = (g.tab[i - 1] - g.tab[i - 2]) / (g.alt[i - 1] - g.alt[i - 2]);
+            const double blin = g.tab[i - 1] - alin * g.alt[i - 1];
+            tg_zlim = TAUABS_MAX;
+            zlim = (tg_zlim - blin) / alin;
+            t_first = T_FIRST;
+            ttot_zlim = ta * exp(-zlim / ha) + tr * exp(-zlim / hr) + tg_zlim;
+            t_layer = (ttot_zlim - t_first) / (OS_NT - a.nt_ng - 2);
+            t_layer = fmax(t_layer, TCOUCHE);
+        } else {
+            zlim = 0.; tg_zlim = tgtot;
+            if ((ttot / OS_NT_MIN) <= T_FIRST) { t_layer = ttot / OS_NT_MIN; t_first = t_layer; }
+            else if ((ttot / OS_NT_MIN) < TCOUCHE) { t_first = T_FIRST; t_layer = (ttot - t_first) / OS_NT_MIN; }
+            else { t_first = T_FIRST; const int n0 = (int)((ttot - t_first) / TCOUCHE); t_layer = (ttot - t_first) / n0; }
+        }
+        nt = 1;
+        double z = TOA, zing = a.z_ng[1];
+        double hmol_p = 0., haer_p = 0., habs_p = 0., h_p = 0.;   // level nt-1
+        int ing = 1;
+        ttot_zlim = ta * exp(-zlim / ha) + tr * exp(-zlim / hr) + tg_zlim;
+        H[0] = 0.;
+        while ((ttot_zlim - h_p) > t_layer) {
+            const int i = nt;
+            if (i > OS_NT - 1 || i >= a.lp - 1) { bad = true; break; }
+            double vr, va, vg;
+            if (i == 1) {
+                double dtau = 0.;
+                while (dtau < t_first) {
+                    z = z - DELTA_Z;
+                    const int j = g.seg(z);
+                    if (z <= g.alt[0]) {
+                        const double zz = (z - g.alt[j - 2]) / (g.alt[j - 1] - g.alt[j - 2]);
+                        vg = (1 - zz) * g.tab[j - 2] + zz * g.tab[j - 1];
+                    } else vg = 0.;
+                    vr = tr * exp(-z / hr); va = ta * exp(-z / ha);
+                    dtau = vr + va + vg;
+                }
+                ing = 1;
+            } else {
+                z = disc(t_layer, ta, ha, tr, hr, g, h_p, Z[1], tg_zlim, zlim);
+            }
+            if (z <= zing) { z = zing; ing = ing + 1; zing = a.z_ng[min(ing, a.nt_ng)]; }
+            else if ((z - zing) <= DZ) { ing = ing + 1; zing = a.z_ng[min(ing, a.nt_ng)]; }
+            Z[i] = z;
+            const int j = g.seg(z);
+            if (z > g.alt[0]) vg = g.tab[j - 2];
+            else {
+                const double zz = (z - g.alt[j - 2]) / (g.alt[j - 1] - g.alt[j - 2]);
+                vg = (1 - zz) * g.tab[j - 2] + zz * g.tab[j - 1];
+            }
+            vr = tr * exp(-z / hr); va = ta * exp(-z / ha);
+            const double hm = vr, hae = va, hab = vg;
+            h_p = va + vr + vg;
+            H[i] = h_p;
+            va = va - haer_p; vr = vr - hmol_p; vg = vg - habs_p;
+            XD[i] = va / (va + vr + vg); YD[i] = vr / (va + vr + vg);
+            hmol_p = hm; haer_p = hae; habs_p = hab;
+            nt = nt + 1;
+        }
+        if (!bad) {
+            // limit level (ground, or the altitude where the gas optical depth reaches the threshold)
+            double hmol_q = hmol_p, haer_q = haer_p, habs_q = habs_p;      // level nt-1 ...
+            if ((Z[nt - 1] - zlim) <= DZ) {
+                // the last computed level is dropped: level nt-1 is the one before it -- recompute its parts from Z
+                nt = nt - 1;
+                const double zq = Z[nt - 1];
+                if (nt - 1 == 0) { hmol_q = 0.; haer_q = 0.; habs_q = 0.; }
+                else {
+                    hmol_q = tr * exp(-zq / hr); haer_q = ta * exp(-zq / ha);
+                    const int j = g.seg(zq);
+                    if (zq > g.alt[0]) habs_q = g.tab[j - 2];
+                    else {
+                        const double zz = (zq - g.alt[j - 2]) / (g.alt[j - 1] - g.alt[j - 2]);
+                        habs_q = (1 - zz) * g.tab[j - 2] + zz * g.tab[j - 1];
+                    }
+                }
+            }
+            Z[nt] = zlim;
+            double vr = tr * exp(-zlim / hr), va = ta * exp(-zlim / ha), vg = tg_zlim;
+            const double hm = vr, hae = va, hab = vg;
+            H[nt] = vr + va + tg_zlim;
+            va = va - haer_q; vr = vr - hmol_q; vg = vg - habs_q;
+            XD[nt] = va / (va + vr + vg); YD[nt] = vr / (va + vr + vg);
+            Z[0] = TOA; XD[0] = XD[1]; YD[0] = YD[1]; H[0] = 0.;
+            if (strong) {
+                nt = nt + 1;
+                if (nt > OS_NT || nt >= a.lp) bad = true;
+                else {
+                    H[nt] = (tr + ta) + tgtot;
+                    vr = tr - hm; va = ta - hae; vg = tgtot - hab;
+                    XD[nt] = va / (va + vr + vg); YD[nt] = vr / (va + vr + vg);
+                    Z[nt] = 0.;
+                }
+            }
+        }
+    }
+    if (bad) {
+        a.nt[b] = -1; a.iborm[b] = 0;
+        if (a.jout) { a.jout[b] = 0; a.zz[b] = 0.; }
+        for (int k = 0; k < 4; k++) a.scal[4 * b + k] = 0.;
+        return;
+    }
+    // PROFIL file round trip (SOS_PROFIL.F:1084 format 20 -> SOS.F:515 format 70)
+    for (int i = 0; i <= nt; i++) { Z[i] = rt_f10_5(Z[i]); H[i] = rt_e15_8(H[i]); XD[i] = rt_e15_8(XD[i]); YD[i] = rt_e15_8(YD[i]); }
+    const double ttot_vrai = H[nt];
+    // truncation rescale (SOS.F:521-543) and IBORM (:549-550)
+    bool lta = true;
+    if (a.a_tronc != 0.) {
+        double htr_p = H[0], h_prev = H[0];
+        for (int i = 1; i <= nt; i++) {
+            const double dh = H[i] - h_prev;
+            h_prev = H[i];
+            const double va = XD[i] * dh;
+            const double vatr = va * (1 - a.piz * 0.5 * a.a_tronc);
+            const double vr = YD[i] * dh;
+            const double vg = (1 - XD[i] - YD[i]) * dh;
+            const double htr = (vatr + vr + vg) + htr_p;
+            XD[i] = vatr / (vatr + vr + vg);
+            YD[i] = vr / (vatr + vr + vg);
+            H[i] = htr;
+            htr_p = htr;
+        }
+    }
+    for (int i = 0; i <= nt; i++) { XD[i] = XD[i] * a.piztr; if (XD[i] != 0.) lta = false; }
+    for (int i = nt + 1; i < a.lp; i++) { H[i] = 0.; XD[i] = 0.; YD[i] = 0.; Z[i] = 0.; }
+    a.nt[b] = nt;
+    a.iborm[b] = lta ? min(2, a.smax) : a.smax;
+    double tauout = H[0];
+    if (a.jout) {
+        int j = 0;
+        double zz = 0.;
+        if (a.zout != -1.0) {                                              // SOS.F:570-582, SOS_OS.F:1514-1520
+            j = 1;
+            while (j < nt && a.zout < Z[j]) j++;
+            zz = (a.zout - Z[j - 1]) / (Z[j] - Z[j - 1]);
+            tauout = (1 - zz) * H[j - 1] + zz * H[j];
+        }
+        a.jout[b] = j; a.zz[b] = zz;
+    }
+    a.scal[4 * b + 0] = 0.;
+    a.scal[4 * b + 1] = H[nt];           // TTOT_TRONC
+    a.scal[4 * b + 2] = ttot_vrai;       // TTOT_VRAI
+    a.scal[4 * b + 3] = tauout;
+}
+
+void launch_profile(const ProfileArgs &a, hipStream_t st)
+{
+    k_profile<<<(a.nb + 63) / 64, 64, 0, st>>>(a);
+}

@@ -135,6 +135,37 @@ class SosContext:
         return dict(nb=nb, lp=lp, perm=perm, nt=_dev_i32(nt, d), iborm=_dev_i32(iborm, d), prof=_dev_f64(prof, d),
                     jout=None if jout is None else _dev_i32(jout, d), zz=None if zz is None else _dev_f64(zz, d))
 
+    def make_profiles(self, nb, tr, hr, ta, ha, altabs=None, tabs=None, *, a_tronc=0.0, piz=1.0, piztr=1.0, zout=-1.0,
+                      lp=608):
+        """SOS_PROFILE (IPROFIL=1) + SOS_DISC + the SOS.F rescale for nb CKD bins ON THE DEVICE (sosgpu_profile):
+        tabs[nb][nblev] is each bin's cumulative gas absorption optical depth on the descending altitude grid
+        altabs[nblev] (None: no gas).  Returns the same dict upload_bins returns (ready for solve()), plus `zprof` and
+        the per-bin scalars `scal` [nb][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT} that aggregate() takes.
+        Bins whose profile needs more than CTE_OS_NT levels come back with nt = -1 (the reference's IER = -1)."""
+        d = self.device
+        t_alt = t_tab = None
+        nblev = 0
+        if tabs is not None:
+            t_tab = _dev_f64(np.atleast_2d(np.asarray(tabs, dtype=np.float64)), d)
+            t_alt = _dev_f64(np.asarray(altabs, dtype=np.float64), d)
+            nblev = int(t_alt.numel())
+            if t_tab.shape != (nb, nblev):
+                raise ValueError("tabs must be [nb][len(altabs)]")
+        prof = torch.zeros((nb, 3, lp), dtype=torch.float64, device=d)
+        zprof = torch.zeros((nb, lp), dtype=torch.float64, device=d)
+        nt = torch.zeros(nb, dtype=torch.int32, device=d)
+        iborm = torch.zeros(nb, dtype=torch.int32, device=d)
+        scal = torch.zeros((nb, 4), dtype=torch.float64, device=d)
+        jout = zz = None
+        if zout != -1.0:
+            jout = torch.zeros(nb, dtype=torch.int32, device=d)
+            zz = torch.zeros(nb, dtype=torch.float64, device=d)
+        capi.check(capi.lib().sosgpu_profile(self._h, nb, tr, hr, ta, ha, 1, nblev, _ptr(t_alt), _ptr(t_tab),
+                                             a_tronc, piz, piztr, zout, lp, _ptr(prof), _ptr(nt), _ptr(iborm),
+                                             _ptr(zprof), _ptr(jout), _ptr(zz), _ptr(scal), self._stream()),
+                   "sosgpu_profile")
+        return dict(nb=nb, lp=lp, perm=None, nt=nt, iborm=iborm, prof=prof, jout=jout, zz=zz, zprof=zprof, scal=scal)
+
     def alloc_outputs(self, nb):
         d = self.device
         return dict(rec=torch.empty((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),

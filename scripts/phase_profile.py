@@ -6,9 +6,10 @@ import numpy as np, torch
 pkg = importlib.import_module("radiativetransfer-sos_amd")
 S = pkg.synth
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 mu, w, n0 = S.gauss_angles(40, 35.0)
 al, be, ga, ze = S.hg_phase(80, 0.75)
-bins = S.ckd_bins(nb, 30, seed=1234)
+bins = S.ckd_bins(nb, nt, seed=1234)
 h, x, y, iborm = S.rescale_profile(bins["h"], bins["xdel"], bins["ydel"], 0.0, 0.95, 0.95, 80)
 cx = pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=iborm, ro=0.1)
 b = cx.upload_bins(h, x, y)

@@ -156,3 +156,32 @@ def compare_records(a, b, rtol=1e-9, what=""):
     bad = err > tol
     assert not bad.any(), "%s: %d entries exceed tolerance; worst err/tol %.3g" % (what, bad.sum(), (err / tol).max())
     return float((err / np.maximum(np.abs(b), 1e-3 * scale)).max())
+
+
+# ---- SOS_PROFILE cases: name -> (tr, hr, ta, ha, gas scale k or None, gas scale height) -------------
+PROFILE_CASES = {
+    "nogas": (0.0948, 8.0, 0.3, 2.0, None, 7.0),
+    "ray_only": (0.0948, 8.0, 0.0, 2.0, None, 7.0),
+    "thin": (0.01, 8.0, 0.005, 2.0, None, 7.0),
+    "thick_aer": (0.0948, 8.0, 1.5, 1.5, None, 7.0),
+    "gas_weak": (0.0948, 8.0, 0.3, 2.0, 0.4, 7.0),
+    "gas_mid": (0.0948, 8.0, 0.3, 2.0, 1.2, 7.0),
+    "gas_strong": (0.0948, 8.0, 0.3, 2.0, 8.0, 7.0),
+    "gas_very_strong": (0.0948, 8.0, 0.1, 3.0, 60.0, 5.0),
+    "gas_ray": (0.0948, 8.0, 0.0, 2.0, 0.7, 7.0),
+    "gas_thin": (0.004, 8.0, 0.002, 2.0, 0.003, 7.0),
+    "gas_h2o_like": (0.02, 8.0, 0.15, 2.0, 0.9, 2.0),
+}
+
+
+def profile_case(name):
+    """Inputs of one SOS_PROFILE case: dict(tr, hr, ta, ha, altabs[50] | None, tabs[50] | None).  The absorption profile is
+    a synthetic exponential column sampled on 50 descending altitudes (CTE_ABS_NBLEV levels from 120 km to the ground,
+    zero at the top level like the reference's profiles)."""
+    tr, hr, ta, ha, k, hg = PROFILE_CASES[name]
+    if k is None:
+        return dict(tr=tr, hr=hr, ta=ta, ha=ha, altabs=None, tabs=None)
+    alt = np.concatenate([np.linspace(120.0, 30.0, 10), np.linspace(28.0, 0.0, 40)])
+    tab = k * np.exp(-alt / hg)
+    tab[0] = 0.0
+    return dict(tr=tr, hr=hr, ta=ta, ha=ha, altabs=alt, tabs=tab)

@@ -126,7 +126,23 @@ def gen_sos_proc():
         print("sos_proc", name, "nblum", out[0], "i_up[0,:3]", out[5][0, :3])
 
 
+def gen_profile():
+    d = {}
+    for name in cases.PROFILE_CASES:
+        c = cases.profile_case(name)
+        r = R.sos_profile(c["tr"], c["hr"], c["ta"], c["ha"], c["altabs"], c["tabs"])
+        assert r["ier"] == 0
+        d[name + "_nt"] = np.int32(r["nt"])
+        for k in ("zprof", "h", "xdel", "ydel"):
+            d[name + "_" + k] = r[k]
+        print("profile", name, "NT", r["nt"])
+    np.savez_compressed(os.path.join(HERE, "sos_profile.npz"), **d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "profile":
+        gen_profile()
+        sys.exit(0)
     if len(sys.argv) > 1:                 # python make_golden.py <sos_os case> ...: only these SOS_OS fixtures
         gen_sos_os(sys.argv[1:])
         sys.exit(0)
@@ -135,3 +151,4 @@ if __name__ == "__main__":
     gen_trphi()
     gen_noyaux()
     gen_sos_os()
+    gen_profile()
