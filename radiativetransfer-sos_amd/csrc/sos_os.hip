@@ -560,17 +560,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                         for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
                             for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
-                    if (BIG) {                                 // stage the chunk: scratch -> LDS (16 B per lane, coalesced)
-                        __syncthreads();
-                        for (int q = t; q < COLS * KH; q += NTH) {
-                            const int col = q / KH, r = q % KH;                    // v2d index r within [X+ | X-]
-                            const int row = (r < KH / 2) ? 2 * r : KHM + 2 * r - KH;
-                            v2d v = {0., 0.};
-                            if (l0 + col <= nt) v = *reinterpret_cast<const v2d *>(fld + (size_t)(l0 + col) * FS + row);
-                            *reinterpret_cast<v2d *>(cbuf + (size_t)col * FS + row) = v;
-                        }
-                        __syncthreads();
-                    }
+                    // BIG: the B operands of this chunk are read straight from the scratch field (16 B per lane, 64 B
+                    // contiguous per column and k-pair; the four waves read the same lines, served by the CU's L1): no
+                    // staging copy and no barrier in front of the contraction.  Levels above nt are zero in the scratch.
+                    const double *bxc = BIG ? fld + (size_t)(l0 + (lane & 15)) * FS + 2 * (lane >> 4) : bx;
                     const double *mpa = cx.mp_aer + (size_t)s * mper;
                     const double *vtp = cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128;
                     const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
@@ -578,18 +571,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     auto contract = [&](auto na_tag) {
                         constexpr int NA = decltype(na_tag)::value;
                         if (s > 2)
-                            gemm_source<NA, -1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,
+                            gemm_source<NA, -1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
                                                                        xdel + l0, ydel + l0, lane, wv);
                         else if (s & 1)
-                            gemm_source<NA, 1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,
+                            gemm_source<NA, 1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
                                                                       xdel + l0, ydel + l0, lane, wv);
                         else
-                            gemm_source<NA, 0, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,
+                            gemm_source<NA, 0, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
                                                                       xdel + l0, ydel + l0, lane, wv);
                     };
                     if (tile_b) contract(std::integral_constant<int, RTWH>());
                     else if (tile_a) contract(std::integral_constant<int, 1>());
-                    __syncthreads();
+                    __syncthreads();             // non-BIG: every wave has read the field; BIG: previous chunk copied out
                     PH(2);
                     // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
                     // accumulators are exact zeros (zero operator rows, zero field columns) and are stored as such.
