@@ -159,7 +159,7 @@ int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
 /* Per-bin atmospheric profiles on the device: SOS_PROFILE for IPROFIL = 1 (src/SOS_PROFIL.F:224-1170) with SOS_DISC
  * (:1210-1332), the PROFIL-file round trip (formats F10.5 / E15.8, SOS_PROFIL.F:1084,1150 -> SOS.F:515,692), the truncation
  * rescale and IBORM of SOS (src/SOS.F:521-550), TAUOUT / TTOT (SOS.F:567-589) and the output level of SOS_OS.F:1514-1520,
- * for nb CKD bins at once.  Replaces the per-bin calls `CALL SOS_PROFILE` (SOS_PROC.F:3509) + the read in `SOS`.
+ * for nb CKD bins at once.  Replaces the per-bin calls `CALL SOS_PROFILE` (SOS_PROC.F:3518) + the read in `SOS`.
  *   tr, hr, ta, ha      Rayleigh / aerosol optical thickness and scale heights of the wavelength
  *   d_tabs[nb][nblev]   cumulative gas absorption optical depth of every bin on the altitude grid d_altabs[nblev]
  *                       (descending, ground last; CTE_ABS_NBLEV = 50 in the reference); NULL = no gas (ABSPROFIL = 7)
