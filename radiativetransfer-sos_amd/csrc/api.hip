@@ -99,9 +99,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
-    d.kp = sos_round_up(6 * N, 8); d.ks2 = d.kp / 8;
-    const int rt = (6 * N + 15) / 16;
-    d.rtp = 4 * ((rt + 3) / 4);
+    d.kp = sos_round_up(6 * N, 8);
     d.kh = sos_round_up(3 * N, 8); d.ks2h = d.kh / 8;
     d.rtph = (d.kh + 15) / 16;
     d.os_nb = B; d.smax = iborm_max;
@@ -160,8 +158,8 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
         sosgpu_destroy(cx);
         return rc;
     }
-    hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double));
-    hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double));
+    HIPCHK(hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double)));
+    HIPCHK(hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double)));
     if (hipEventCreate(&cx->ev0) != hipSuccess || hipEventCreate(&cx->ev1) != hipSuccess) {
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;
@@ -173,12 +171,13 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
 extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
 {
     if (!cx) return SOSGPU_OK;
-    hipSetDevice(cx->device);
-    for (void *p : cx->allocs) hipFree(p);
-    if (cx->scratch) hipFree(cx->scratch);
-    if (cx->prof_ng) hipFree(cx->prof_ng);
-    if (cx->ev0) hipEventDestroy(cx->ev0);
-    if (cx->ev1) hipEventDestroy(cx->ev1);
+    // teardown: nothing useful can be done with a failing free, errors are deliberately dropped
+    (void)hipSetDevice(cx->device);
+    for (void *p : cx->allocs) (void)hipFree(p);
+    if (cx->scratch) (void)hipFree(cx->scratch);
+    if (cx->prof_ng) (void)hipFree(cx->prof_ng);
+    if (cx->ev0) (void)hipEventDestroy(cx->ev0);
+    if (cx->ev1) (void)hipEventDestroy(cx->ev1);
     delete cx;
     return SOSGPU_OK;
 }
@@ -211,7 +210,7 @@ extern "C" int sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out)
     HIPCHK(hipMalloc((void **)&tmp, cnt * sizeof(double)));
     launch_noyaux_fetch(cx->d, is, tmp, nullptr);
     hipError_t e = hipMemcpy(out, tmp, cnt * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(tmp);
+    (void)hipFree(tmp);
     HIPCHK(e);
     return SOSGPU_OK;
 }
@@ -243,7 +242,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         const size_t need = per_bin * per_launch;
         if (need > cx->scratch_doubles) {
             HIPCHK(hipStreamSynchronize(st));
-            if (cx->scratch) hipFree(cx->scratch);
+            if (cx->scratch) (void)hipFree(cx->scratch);
             cx->scratch = nullptr;
             cx->scratch_doubles = 0;
             HIPCHK(hipMalloc((void **)&cx->scratch, need * sizeof(double)));
@@ -446,7 +445,7 @@ extern "C" int sosgpu_glitter(int device, int n, const double *mu, const double 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d_buf);
+    (void)hipFree(d_buf);
     HIPCHK(e);
     return SOSGPU_OK;
 }

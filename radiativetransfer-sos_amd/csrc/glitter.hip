@@ -41,7 +41,7 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // il[pair], e[pair][os_nm+1] (zero beyond IL); pairs ordered (I1 = 1..N, I2 = 1..I1)
-__global__ __launch_bounds__(64) void k_gsf(int n, const double *__restrict__ mu, double sig, int os_nm,
+__global__ __launch_bounds__(64) void k_gsf(const double *__restrict__ mu, double sig, int os_nm,
                                            int32_t *__restrict__ il_out, double *__restrict__ e_out)
 {
     __shared__ double u[PH_NU + 1];
@@ -251,7 +251,7 @@ void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns,
                     int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st)
 {
     const int npairs = n * (n + 1) / 2;
-    k_gsf<<<npairs, 64, 0, st>>>(n, d_mu, sig, os_nm, d_il, d_e);
+    k_gsf<<<npairs, 64, 0, st>>>(d_mu, sig, os_nm, d_il, d_e);
     const size_t sh = ((size_t)(os_nm + 1) + 12 * (size_t)(os_ns + 1)) * sizeof(double);
     k_mat_reflexion<<<npairs, 128, sh, st>>>(n, d_mu, 1. / sig, os_nb, os_ns, os_nm, d_fcoef, d_il, d_e, d_rsurf);
 }

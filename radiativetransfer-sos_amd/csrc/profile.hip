@@ -73,9 +73,7 @@ __device__ __forceinline__ double rt_f10_5(double v) { return copysign(round_sca
 
 struct GasProf {
     const double *alt, *tab;
-    int n;
-    // linear interpolation of the absorption optical depth at altitude z, clamped above the profile top
-    // (SOS_PROFIL.F:694-705; `outside` selects the two conventions the reference uses above ALTABS(1))
+    // index J of the absorption-profile segment holding altitude z: ALTABS(J-1) > z >= ALTABS(J) (SOS_PROFIL.F:694-697)
     __device__ __forceinline__ int seg(double z) const
     {
         int j = 2;
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a)
     double *H = a.prof + (size_t)b * 3 * a.lp, *XD = H + a.lp, *YD = XD + a.lp;
     double *Z = a.zprof + (size_t)b * a.lp;
     GasProf g;
-    g.alt = a.altabs; g.n = a.nblev;
+    g.alt = a.altabs;
     g.tab = a.tabs ? a.tabs + (size_t)b * a.nblev : nullptr;
     const double tgtot = g.tab ? g.tab[a.nblev - 1] : 0.0;
     int nt;

@@ -26,7 +26,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 struct SosDev {                 // per-wavelength device context, passed by value to the kernels
     int n, w, r6;               // N, 2N+1, 6N
-    int kp, ks2, rtp;           // order-1 vector stride (6N padded to 8); legacy full-operator sizes (unused by the solver)
+    int kp;                     // order-1 vector stride (6N padded to 8)
     int kh, ks2h, rtph;         // half system: 3N padded to 8, kh/8, 16-row tiles per system ceil(kh/16)
     int os_nb, smax;            // OS_NB, iborm_max
     int n0, imat_surf, ifresnel, igmax, ipolar;
@@ -39,7 +39,7 @@ struct SosDev {                 // per-wavelength device context, passed by valu
     const double *coef;         // [4][os_nb+1] alpha,beta,gamma,zeta (polarisation cut applied)
     const double *fres;         // [3][N] F11,F12,F33 at mu_k (SOS_OS.F:1753-1780)
     double *prt;                // [smax+1][3][os_nb+1][W]  P,R,T generalised spherical functions
-    double *mp_aer;             // [smax+1][rtp*ks2*128]
+    double *mp_aer;             // [smax+1][2 systems][rtph*ks2h*128] parity-form aerosol operators (packed A fragments)
     double *mp_vt;              // [3][ks2h*128]  molecular operator, projection factor V^T (one 16-row tile, rows 0..3 used)
     double *mp_uf;              // [3][rtph*64]   molecular operator, expansion factor U (K = 4)
     double *sv;                 // [smax+1][4][kp]: order-1 vectors aer, ray, fresnel-aer, fresnel-ray
