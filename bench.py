@@ -86,7 +86,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    use_dist = args.gpus > 1 or world > 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
@@ -175,7 +176,7 @@ def main():
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
