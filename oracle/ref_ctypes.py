@@ -404,3 +404,41 @@ def sos_profile(tr, hr, ta, ha, altabs=None, tabs=None, absprofil=1):
         return dict(ier=0, nt=nt.value, zprof=a[:, 0].copy(), h=a[:, 1].copy(), xdel=a[:, 2].copy(), ydel=a[:, 3].copy())
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sos_aggregate(n, rec_bins, nf, aik, scal_bins):
+    """Reference SOS_AGGREGATE (SOS_AGGREGATE.F:172) called once per bin, in bin order, exactly as the bin loop of
+    SOS_PROC does (SOS_PROC.F:3564): rec_bins [nb][fmax][3][2n+1] (I,Q,U), nf [nb] records per bin, scal_bins [nb][7] =
+    TDIFMUS, EMOINS, EPLUS, TTOT_TRONC, TTOT_VRAI, TAUOUT, (unused).  Returns (out_rec [F][3][2n+1], out_scal[7])."""
+    rec_bins = np.asarray(rec_bins, dtype=np.float64)
+    nb = rec_bins.shape[0]
+    tmp = tempfile.mkdtemp(prefix="sosref_")
+    try:
+        f_tmp, f_agg, f_res = (os.path.join(tmp, x) for x in ("OS_TMP.bin", "OS_AGG_TMP.bin", "SOS_Result.bin"))
+        acc = [C.c_double(0.0) for _ in range(6)]          # TTOT_TRONC, TTOT_VRAI, TAUOUT, TDIFMUS, EMOINS, EPLUS
+        tdifmug = np.zeros(2 * NBMU_MAX + 1)
+        tdifmug_tmp = np.zeros(2 * NBMU_MAX + 1)
+        for b in range(nb):
+            write_fourier_file(f_tmp, rec_bins[b, :nf[b]])
+            sb = scal_bins[b]
+            ier = C.c_int32(0)
+            d = lambda v: C.byref(C.c_double(float(v)))
+
+            def call():
+                lib().sos_aggregate_(C.byref(C.c_int32(n)), d(aik[b]), _fstr(f_tmp), d(sb[3]), d(sb[4]), d(sb[5]),
+                                     d(sb[0]), _p(tdifmug_tmp), d(sb[1]), d(sb[2]), _fstr(f_agg), _fstr(f_res),
+                                     C.byref(acc[0]), C.byref(acc[1]), C.byref(acc[2]), C.byref(acc[3]), _p(tdifmug),
+                                     C.byref(acc[4]), C.byref(acc[5]), C.byref(ier),
+                                     C.c_size_t(LENFIC2), C.c_size_t(LENFIC2), C.c_size_t(LENFIC2))
+
+            _big_stack_call(call)
+            assert ier.value == 0, ier.value
+        w = 2 * n + 1
+        out = []
+        for r in read_fortran_records(f_res):
+            q, u, i = r[:w], r[w:2 * w], r[2 * w:3 * w]
+            out.append(np.stack([i, q, u]))
+        return np.array(out), np.array([acc[3].value, acc[4].value, acc[5].value, acc[0].value, acc[1].value,
+                                        acc[2].value, 0.0])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -126,6 +126,23 @@ def gen_sos_proc():
         print("sos_proc", name, "nblum", out[0], "i_up[0,:3]", out[5][0, :3])
 
 
+def gen_aggregate():
+    """SOS_AGGREGATE called once per bin in bin order (the reference appends one all-zero record per call after the
+    first; those trailing records are part of the fixture)."""
+    rng = np.random.default_rng(3)
+    nb, fmax, n = 5, 7, 9
+    w = 2 * n + 1
+    rec = rng.normal(size=(nb, fmax, 3, w))
+    rec[:, :, :, n] = 0
+    nf = np.array([7, 3, 5, 1, 6], dtype=np.int32)
+    aik = rng.dirichlet(np.ones(nb))
+    scal = np.abs(rng.normal(size=(nb, 7)))
+    out_rec, out_scal = R.sos_aggregate(n, rec, nf, aik, scal)
+    np.savez_compressed(os.path.join(HERE, "aggregate_n9.npz"), n=n, rec=rec, nf=nf, aik=aik, scal=scal,
+                        out_rec=out_rec, out_scal=out_scal)
+    print("aggregate ok", out_rec.shape)
+
+
 def gen_profile():
     d = {}
     for name in cases.PROFILE_CASES:
@@ -142,6 +159,10 @@ def gen_profile():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "profile":
         gen_profile()
+    gen_aggregate()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "aggregate":
+        gen_aggregate()
         sys.exit(0)
     if len(sys.argv) > 1:                 # python make_golden.py <sos_os case> ...: only these SOS_OS fixtures
         gen_sos_os(sys.argv[1:])
@@ -152,3 +173,4 @@ if __name__ == "__main__":
     gen_noyaux()
     gen_sos_os()
     gen_profile()
+    gen_aggregate()

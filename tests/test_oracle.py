@@ -84,6 +84,18 @@ def test_aggregate_serial_semantics(oracle):
     assert np.allclose(out_scal[3:6], -np.log((aik[:, None] * np.exp(-scal[:, 3:6])).sum(0)), rtol=1e-12)
 
 
+def test_aggregate_vs_reference_golden(oracle):
+    """oracle.aggregate == the real SOS_AGGREGATE called bin by bin (fixture made by make_golden.py aggregate): records
+    and the six scalars bit for bit; the reference file additionally carries one all-zero record per call after the first."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aggregate_n9.npz"))
+    out_rec, out_scal = oracle.aggregate(g["rec"], g["nf"], g["aik"], g["scal"])
+    f = len(out_rec)
+    assert f == int(g["nf"].max())
+    assert np.array_equal(out_rec, g["out_rec"][:f]) and np.all(g["out_rec"][f:] == 0)
+    assert np.array_equal(out_scal[:6], g["out_scal"][:6])
+
+
 def test_profile_rescale_matches_host(oracle, pkg):
     """Host-side restatement of SOS.F:523-550 (synth.rescale_profile) == oracle's."""
     S = pkg.synth
