@@ -159,7 +159,6 @@ def gen_profile():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "profile":
         gen_profile()
-    gen_aggregate()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "aggregate":
         gen_aggregate()
