@@ -680,17 +680,28 @@ static size_t lds_bytes_for(int nw, int rtw, int ct, bool big)
     return dbl * sizeof(double);
 }
 
+// Variant of a problem size: waves per workgroup, row tiles per wave, column tiles per chunk, field in LDS or in HBM.
+//   NT+1 <= 32 : field in LDS, two column tiles, 4 waves (two workgroups per CU) -- the flagship
+//   NT+1 <= 64 : field in LDS, four column tiles; for 21 < N <= 42 EIGHT waves with one row tile each, so that the
+//                accumulators stay at 64 VGPRs and the CU still hosts two waves per SIMD although the 64-level field
+//                leaves room for one workgroup only (68.6k vs 61.3k bins/s for <4,2,4> at N = 41, NT = 60)
+//   NT+1 >  64 : field in the HBM scratch, two column tiles per contraction pass, two workgroups per CU (the 8-wave
+//                four-tile form was slower there: 21.8k vs 26.5k bins/s at NT = 100)
+//   N > 42     : eight waves, two row tiles each, two column tiles (LDS holds 32 levels of the 6N x 8 B rows)
+static void sos_os_shape(int n, int nt_max, int *nw, int *rtw, int *ct, int *big)
+{
+    const int kh = sos_round_up(3 * n, 8);
+    if (kh > 128) { *nw = 8; *rtw = 2; *ct = 2; *big = nt_max + 1 > 32; return; }
+    if (nt_max + 1 <= 32 || nt_max + 1 > 64) { *nw = 4; *rtw = kh <= 64 ? 1 : 2; *ct = 2; *big = nt_max + 1 > 64; return; }
+    *nw = kh <= 64 ? 4 : 8; *rtw = 1; *ct = 4; *big = 0;
+}
+
 // returns 0 and the variant (nw waves, rtw row tiles per wave and system, ct column tiles, big) or UNSUPPORTED
 int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_bytes, int *big)
 {
     if (n < 1 || n > 85 || nt_max < 1 || nt_max > 1023) return SOSGPU_E_UNSUPPORTED;
-    const int kh = sos_round_up(3 * n, 8);
-    const int w = kh <= 128 ? 4 : 8;
-    const int r = kh <= 64 ? 1 : 2;
-    int c = 2, b = 0;
-    if (nt_max + 1 <= 32) c = 2;
-    else if (nt_max + 1 <= 64 && w == 4 && lds_bytes_for(w, r, 4, false) <= 160 * 1024) c = 4;
-    else b = 1;
+    int w, r, c, b;
+    sos_os_shape(n, nt_max, &w, &r, &c, &b);
     const size_t lb = lds_bytes_for(w, r, c, b);
     if (lb > 160 * 1024) return SOSGPU_E_UNSUPPORTED;
     if (nw) *nw = w;
@@ -703,8 +714,8 @@ int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_by
 
 size_t sos_os_scratch_doubles(int n, int lpb)
 {
-    const int kh = sos_round_up(3 * n, 8);
-    const int w = kh <= 128 ? 4 : 8, r = kh <= 64 ? 1 : 2;
+    int w, r, c, b;
+    sos_os_shape(n, 1023, &w, &r, &c, &b);            // the field-in-HBM shape of this N
     return (size_t)lpb * (sos_fs(w, r) + sos_ns(w, r) + 7);
 }
 
@@ -738,7 +749,7 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     if (nw == NWV && rtw == R && ct == C && big == B)                                     \
         return zo ? launch_variant<NWV, R, C, B, true>(cx, bn, lds, st) : launch_variant<NWV, R, C, B, false>(cx, bn, lds, st);
     V(4, 1, 2, 0) V(4, 2, 2, 0) V(8, 2, 2, 0)
-    V(4, 1, 4, 0) V(4, 2, 4, 0)
+    V(4, 1, 4, 0) V(8, 1, 4, 0)
     V(4, 1, 2, 1) V(4, 2, 2, 1) V(8, 2, 2, 1)
 #undef V
     return SOSGPU_E_UNSUPPORTED;
