@@ -100,7 +100,22 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
     d.kp = sos_round_up(6 * N, 8);
-    d.kh = sos_round_up(3 * N, 8); d.ks2h = d.kh / 8;
+    d.kh = sos_round_up(3 * N, 8);
+    // half-system row order: directions with a non-zero quadrature weight first (component-major), the zero-weight
+    // ones (the solar direction, user angles: SOS_ANGLES gives them weight 0) last.  Their operator COLUMNS vanish, so
+    // the contraction only runs over K = 3 Nw (N = 41: 15 k-pairs instead of 16); their rows are still computed.
+    int nwgt = 0;
+    for (int j = 0; j < N; j++) nwgt += ga[j] != 0.0;
+    if (nwgt < 1) { delete cx; return SOSGPU_E_ARG; }
+    d.ks2h = (3 * nwgt + 7) / 8;
+    std::vector<int32_t> rowmap(d.kh, -1);
+    {
+        int pos = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int c = 0; c < 3; c++)
+                for (int j = 0; j < N; j++)
+                    if ((ga[j] != 0.0) == (pass == 0)) rowmap[pos++] = c * N + j;
+    }
     d.rtph = (d.kh + 15) / 16;
     d.os_nb = B; d.smax = iborm_max;
     d.n0 = wv->n0; d.imat_surf = wv->imat_surf == 1; d.ifresnel = wv->ifresnel == 1 ? 1 : 0;
@@ -149,6 +164,14 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     UP(d.coef, coef.data(), coef.size())
     UP(d.fres, fres.data(), fres.size())
 #undef UP
+    {
+        int32_t *q = nullptr;
+        if ((rc = dev_alloc(cx, &q, rowmap.size()))) { sosgpu_destroy(cx); return rc; }
+        if (hipMemcpy(q, rowmap.data(), rowmap.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            sosgpu_destroy(cx); return SOSGPU_E_HIP; }
+        d.rowmap = q;
+        d.nwgt = nwgt;
+    }
     const size_t per = (size_t)2 * d.rtph * d.ks2h * 128;
     if ((rc = dev_alloc(cx, &d.prt, (size_t)(d.smax + 1) * 3 * (B + 1) * d.w)) ||
         (rc = dev_alloc(cx, &d.mp_aer, (size_t)(d.smax + 1) * per)) ||
@@ -288,7 +311,7 @@ extern "C" int sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, cons
     HIPCHK(hipMemcpy(nt.data(), d_nt, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(no.data(), d_norders, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ig.data(), d_iglast, (size_t)nb * S1 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    const double r6 = 6.0 * cx->d.n, r3 = 3.0 * cx->d.n;
+    const double r6 = 6.0 * cx->d.n, r3 = 3.0 * cx->d.n, k3 = 3.0 * cx->d.nwgt;
     double tot = 0., exe = 0.;
     for (int b = 0; b < nb; b++) {
         const double L = nt[b] + 1.0;
@@ -296,8 +319,8 @@ extern "C" int sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, cons
             const int steps = ig[(size_t)b * S1 + s] - 1;    // scattering orders >= 2 actually computed
             if (steps <= 0) continue;
             double w = 2. * r6 * r6 * L + 12. * r6 * nt[b];  // SURVEY 8d W_step
-            double e = 2. * 2. * r3 * r3 * L + 10. * r6 * nt[b];
-            if (s <= 2) { w += 2. * 3. * r6 * L * 3.; e += 2. * 2. * 4. * r3 * L; }
+            double e = 2. * 2. * r3 * k3 * L + 10. * r6 * nt[b];
+            if (s <= 2) { w += 2. * 3. * r6 * L * 3.; e += 2. * 4. * (r3 + k3) * L; }
             tot += steps * w;
             exe += steps * e;
         }

@@ -141,7 +141,8 @@ template <bool RAY>
 __device__ inline double half_element(const SosDev &cx, int s, int sys, int row, int col)
 {
     const int N = cx.n;
-    const int co = row / N, k = row % N + 1, ci = col / N, j = col % N + 1;
+    const int ro = cx.rowmap[row], cl = cx.rowmap[col];         // half-system positions -> (component, direction)
+    const int co = ro / N, k = ro % N + 1, ci = cl / N, j = cl % N + 1;
     const double sg = sys ? -1. : 1.;
     int X, a, b;
     bool mns = false, neg = false;
@@ -205,7 +206,8 @@ __global__ void k_pack_ray(SosDev cx)
         const int row = lane & 15, col = 8 * m + 2 * (lane >> 4) + e2;
         double v = 0.;
         if (row < 4 && col < 3 * N) {
-            const int ci = col / N, j = col % N + 1;
+            const int cl = cx.rowmap[col];
+            const int ci = cl / N, j = cl % N + 1;
             const double hw = 0.5 * cx.ga[j - 1];
             const double f = (ci == 0) ? P[j] : (ci == 1 ? R[j] : T[j]);
             const double c0[3] = {b2, g2, -g2}, c1[3] = {g2, a2, -a2}, c2[3] = {-g2, -a2, a2};
@@ -221,7 +223,8 @@ __global__ void k_pack_ray(SosDev cx)
         const int row = rt * 16 + (lane & 15), k4 = lane >> 4;
         double v = 0.;
         if (row < 3 * N) {
-            const int co = row / N, k = row % N + 1;
+            const int ro = cx.rowmap[row];
+            const int co = ro / N, k = ro % N + 1;
             if (co == 0) v = (k4 == 0) ? P[k] : (k4 == 3 ? ((s == 0) ? 1. : 0.) : 0.);
             else if (co == 1) v = (k4 == 1) ? R[k] : 0.;
             else v = (k4 == 2) ? T[k] : 0.;

@@ -16,7 +16,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // X^A = X(+mu) + g_c X(-mu), X^B = X(+mu) - g_c X(-mu), g = (+1,+1,-1) for (I,Q,U), the 6N x 6N operator
 // splits into two independent 3N x 3N systems (A couples I^e,Q^e,U^o; B couples I^o,Q^o,U^e):
 //   E^A = M^A X^A, E^B = M^B X^B,   S(+mu) = E^A + E^B,  S(-mu) = g_c (E^A - E^B)
-// which halves the matrix-core work and the operator stream.  Half-system index kk = c*N + (k-1).
+// which halves the matrix-core work and the operator stream.  Half-system positions are listed in SosDev::rowmap:
+// component-major over the directions with a non-zero Gauss weight, then the zero-weight directions (solar / user
+// angles), whose operator columns vanish -- the contraction runs over the first 3 Nw positions only.
 //
 // Packed operator layout (A operand of v_mfma_f64_16x16x4_f64, one f64 per lane), per order s and system:
 //   mp[(((s*2 + sys)*RTPH + rt)*KS2H + m)*128 + lane*2 + e] = M^sys[rt*16 + (lane&15)][8m + 2*(lane>>4) + e]
@@ -27,7 +29,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 struct SosDev {                 // per-wavelength device context, passed by value to the kernels
     int n, w, r6;               // N, 2N+1, 6N
     int kp;                     // order-1 vector stride (6N padded to 8)
-    int kh, ks2h, rtph;         // half system: 3N padded to 8, kh/8, 16-row tiles per system ceil(kh/16)
+    int kh, ks2h, rtph;         // half system: rows 3N padded to 8; k-pairs of the contraction ceil(3 Nw / 8); 16-row tiles ceil(kh/16)
+    int nwgt;                   // Nw: directions with a non-zero quadrature weight
+    const int32_t *rowmap;      // [kh] half-system position -> c*N + (k-1) (weighted directions first), -1 = padding
     int os_nb, smax;            // OS_NB, iborm_max
     int n0, imat_surf, ifresnel, igmax, ipolar;
     double mus;                 // cos(solar zenith) = mu[n0-1]; the reference's TAB = -mus

@@ -311,9 +311,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
     const bool up = wv < HW;               // wave-uniform
     const int kk0 = up ? t : t - 64 * HW;
     const bool active = kk0 < 3 * N;
-    const int kk = active ? kk0 : 0;
-    const int c = kk / N;
-    const int jj = kk % N;                 // 0-based index of |direction|
+    const int kk = active ? kk0 : 0;       // half-system position of this thread's row
+    const int cj = cx.rowmap[kk];          // -> component and direction (weighted directions first, sos_common.h)
+    const int c = cj / N;
+    const int jj = cj % N;                 // 0-based index of |direction|
     const int d = up ? jj : N + jj;
     const int rl = up ? kk : KHM + kk;     // field row of this thread
     const int rsv = c * 2 * N + d;         // row in the order-1 vector tables (sv)
