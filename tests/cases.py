@@ -83,6 +83,9 @@ def make_case(name):
     elif name == "zout_n65_nt45":         # N > 42 with the field in the HBM scratch
         ng, nt, os_nb, g, kabs = 64, 45, 64, 0.7, [0.6]
         kw = dict(ro=0.2, zout=2.5)
+    elif name == "user_angles_n28":       # 24 Gauss + sun + 3 user viewing angles (zero quadrature weight, SOS_ANGLES)
+        ng, nt, os_nb, g, kabs = 24, 30, 48, 0.7, [0.0, 1.0]
+        kw = dict(ro=0.1)
     elif name.startswith("x_"):           # ad-hoc debugging case: x_<ng>_<nt>_<os_nb>_<g>_<zout or -1>
         f = name.split("_")
         ng, nt, os_nb, g, kabs = int(f[1]), int(f[2]), int(f[3]), float(f[4]), [0.0]
@@ -92,6 +95,14 @@ def make_case(name):
     else:
         raise KeyError(name)
     mu, w, n0 = S.gauss_angles(ng, 35.0)
+    if name == "user_angles_n28":
+        # user angles are merged into the descending list with weight 0, exactly like the solar direction
+        extra = np.cos(np.radians([10.0, 47.5, 72.0]))
+        mu_all = np.concatenate([mu, extra]); w_all = np.concatenate([w, np.zeros(3)])
+        order = np.argsort(-mu_all, kind="stable")
+        mus = mu[n0 - 1]
+        mu, w = mu_all[order], w_all[order]
+        n0 = int(np.where(mu == mus)[0][0]) + 1
     if g is None:
         al, be, ga, ze = S.hg_phase(os_nb, 0.0)
     else:
@@ -114,7 +125,7 @@ def make_case(name):
 ALL_CASES = ["rayleigh_n25", "aer_n41", "aer_n41_g09", "fresnel_n41", "nopolar_n41", "zout_n25_nt60",
              "brdf_n13", "brdf_zout_n13", "black_n9", "igmax_n9",
              "rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600",
-             "aer_n21", "zout_n21_nt50", "aer_n49", "fresnel_n80_nt24", "zout_n65_nt45"]
+             "aer_n21", "zout_n21_nt50", "aer_n49", "fresnel_n80_nt24", "zout_n65_nt45", "user_angles_n28"]
 
 
 def run_cpu(mod, case, b):
