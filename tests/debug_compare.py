@@ -1,6 +1,8 @@
+"""Developer aid (test infrastructure): run parity cases on the GPU and print per-order differences against the oracle.
+usage: python tests/debug_compare.py <case> [...]   (case names of tests/cases.py, or x_<ng>_<nt>_<os_nb>_<g>_<zout>)"""
 import sys, importlib, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import cases
 from oracle import oracle_ctypes as O
