@@ -557,6 +557,7 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     if (!cx || nb < 1 || lp < 2 || !d_prof || !d_nt || !d_iborm || !d_zprof || !d_scal) return SOSGPU_E_ARG;
     if ((d_jout == nullptr) != (d_zz == nullptr)) return SOSGPU_E_ARG;
     if (d_tabs && (!d_altabs || nblev < 2)) return SOSGPU_E_ARG;
+    if (d_tabs && nblev > SOS_PROF_NBLEV_MAX) return SOSGPU_E_UNSUPPORTED;
     if (!(hr > 0.) || !(ha > 0.) || tr < 0. || ta < 0.) return SOSGPU_E_ARG;
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;

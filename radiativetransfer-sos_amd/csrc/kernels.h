@@ -21,6 +21,7 @@ void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns,
 void launch_trphi(const SosDev &cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
                   const double *d_phi, int igli, double sigma2, double ind_surf, double *d_out, hipStream_t st);
 
+#define SOS_PROF_NBLEV_MAX 64     // levels of the absorption profile held in LDS (CTE_ABS_NBLEV = 50 in the reference)
 // Per-bin profile discretisation (profile.hip).  *_ng: the no-gas profile of the wavelength (host-computed, device copy).
 struct ProfileArgs {
     int nb, lp, nblev, absprofil, smax, nt_ng;

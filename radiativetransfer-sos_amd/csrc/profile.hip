@@ -15,6 +15,7 @@
 // runs one thread per bin (the level loop is a serial recurrence: each level starts from the optical depth the
 // previous bisection actually reached).  Latency/transcendental-bound: ~NT * 25 bisection steps * 2 exp per bin, no
 // HBM traffic to speak of (50 doubles in, 4 * (NT+1) doubles out per bin).
+#include <algorithm>
 #include "sos_common.h"
 #include "kernels.h"
 
@@ -72,13 +73,19 @@ __device__ double rt_e15_8(double v)
 __device__ __forceinline__ double rt_f10_5(double v) { return copysign(round_scaled(fabs(v), 1e5) / 1e5, v); }
 
 struct GasProf {
-    const double *alt, *tab;
-    // index J of the absorption-profile segment holding altitude z: ALTABS(J-1) > z >= ALTABS(J) (SOS_PROFIL.F:694-697)
+    const double *alt, *tab;     // altitude grid (descending) and cumulative gas optical depth of the bin, in LDS
+    int n;
+    // index J of the absorption-profile segment holding altitude z: first J >= 2 with z >= ALTABS(J), i.e.
+    // ALTABS(J-1) > z >= ALTABS(J) (SOS_PROFIL.F:694-697).  The reference scans J upwards; the grid is monotonic, so a
+    // bisection returns the same J in 6 steps instead of up to 50 dependent loads.
     __device__ __forceinline__ int seg(double z) const
     {
-        int j = 2;
-        while (z < alt[j - 1]) j++;
-        return j;
+        int lo = 2, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (z < alt[mid - 1]) lo = mid + 1; else hi = mid;
+        }
+        return lo;
     }
 };
 
@@ -109,11 +116,15 @@ __device__ double disc(double dt, double ta, double ha, double tr, double hr, co
 
 }  // namespace
 
-// One thread per bin.  prof[b][3][lp] <- H, XDEL, YDEL (after the rescale), zprof[b][lp], nt, iborm, jout, zz,
+// One thread per bin, `bpw` bins per wavefront.  The work of a bin is a long serial chain (latency-bound) and very ragged
+// (NT 100...600, bisection depth varies), so a wavefront is deliberately left mostly EMPTY: with few bins per wave the
+// batch spreads over all 1024 SIMDs and a wave only waits for the slowest of its few bins.
+// prof[b][3][lp] <- H, XDEL, YDEL (after the rescale), zprof[b][lp], nt, iborm, jout, zz,
 // scal[b][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT}; nt[b] = -1 flags a profile that does not fit (IER of the reference).
-__global__ __launch_bounds__(64) void k_profile(ProfileArgs a)
+__global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)threadIdx.x >= bpw) return;          // no barrier below: every thread only touches its own LDS slice
+    const int b = blockIdx.x * bpw + threadIdx.x;
     if (b >= a.nb) return;
     const double TCOUCHE = (double)0.005f, T_FIRST = (double)0.0002f, DELTA_Z = (double)0.05f, DZ = (double)0.001f;
     const double TAUABS_MAX = 1.5, TOA = 120.0;
@@ -121,9 +132,15 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a)
     const double tr = a.tr, hr = a.hr, ta = a.ta, ha = a.ha;
     double *H = a.prof + (size_t)b * 3 * a.lp, *XD = H + a.lp, *YD = XD + a.lp;
     double *Z = a.zprof + (size_t)b * a.lp;
+    // the bin's absorption profile is read thousands of times: keep it (and the altitude grid) in LDS
+    __shared__ double s_alt[SOS_PROF_NBLEV_MAX];
+    __shared__ double s_tab[64][SOS_PROF_NBLEV_MAX + 1];     // +1: odd stride, lanes on different banks
     GasProf g;
-    g.alt = a.altabs;
-    g.tab = a.tabs ? a.tabs + (size_t)b * a.nblev : nullptr;
+    g.n = a.nblev; g.alt = s_alt; g.tab = nullptr;
+    if (a.tabs) {
+        for (int i = 0; i < a.nblev; i++) { s_tab[threadIdx.x][i] = a.tabs[(size_t)b * a.nblev + i]; s_alt[i] = a.altabs[i]; }
+        g.tab = s_tab[threadIdx.x];
+    }
     const double tgtot = g.tab ? g.tab[a.nblev - 1] : 0.0;
     int nt;
     bool bad = a.nt_ng < 1 || a.nt_ng > OS_NT || a.nt_ng >= a.lp;
@@ -287,5 +304,7 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a)
 
 void launch_profile(const ProfileArgs &a, hipStream_t st)
 {
-    k_profile<<<(a.nb + 63) / 64, 64, 0, st>>>(a);
+    // about 2048 wavefronts (2 per SIMD) whatever the batch size
+    const int bpw = std::min(64, std::max(1, (a.nb + 2047) / 2048));
+    k_profile<<<(a.nb + bpw - 1) / bpw, 64, 0, st>>>(a, bpw);
 }
