@@ -50,22 +50,25 @@ __device__ __forceinline__ double uniform_f64(double v)
 }
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// bitwise OR over the workgroup of up to 3 predicate bits (red: NW ints of LDS); two barriers, no FP64 work.
+// bitwise OR over the workgroup of up to 3 predicate bits (red: 2 x NW ints of LDS, the two halves used alternately:
+// `slot` flips on every call, so a wave that runs ahead into the next call writes the other half and ONE barrier per
+// call is enough -- the barrier also publishes whatever the caller wrote to LDS/scratch before).  No FP64 work.
 // (__syncthreads_or only returns a logical OR.)
 template <int NW>
-__device__ __forceinline__ int block_or_bits(int bits, int *red, int wv, int lane)
+__device__ __forceinline__ int block_or_bits(int bits, int *red, int wv, int lane, int &slot)
 {
     int w = 0;
     if (__ballot(bits & 1)) w |= 1;
     if (__ballot(bits & 2)) w |= 2;
     if (__ballot(bits & 4)) w |= 4;
-    if (lane == 0) red[wv] = w;
+    int *r = red + slot * NW;
+    slot ^= 1;
+    if (lane == 0) r[wv] = w;
     __syncthreads();
-    int r = 0;
+    int o = 0;
 #pragma unroll
-    for (int i = 0; i < NW; i++) r |= red[i];
-    __syncthreads();
-    return uniform_i32(r);
+    for (int i = 0; i < NW; i++) o |= r[i];
+    return uniform_i32(o);
 }
 
 // Instruction budget.  FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
 
         double i4 = 0., i5 = 0.;
         double sign = -1.;
+        int red_slot = 0;
         int nord = 0;
 #ifdef SOS_PROFILE_PHASES
         unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 order-1 fill, 1 scan, 2 gemm, 3 writeback, 4 reduce+tests, 5 ground_bc, 6 fourier, 7 init
@@ -513,14 +517,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             int ig = 1, iglast = 1;
             for (;;) {
                 scan_row(bc);                                                        // SOS_OS.F:1025 / 1244
-                __syncthreads();
-                PH(1);
                 if (ig == 1) {                                                       // SOS_OS.F:1094-1137
+                    __syncthreads();
+                    PH(1);
                     i3 = xb; a1 = 0.; d1 = xb; g1 = 0.;
                     if (ZO) { i3lo = xlo; dlo = xlo; i3hi = xhi; dhi = xhi; }
                     bc = ground_bc();
                     PH(5);
                 } else {
+                    PH(1);                                   // formal solution without its barrier wait (that goes to 4)
                     g1 = xb;
                     const double i3n = i3 + g1;
                     int pm = 0;
@@ -530,7 +535,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                         if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
                         if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
                     }
-                    pm = block_or_bits<NW>(pm, reinterpret_cast<int *>(red), wv, lane);
+                    // the barrier inside also ends the formal solution: field and ground values are complete after it
+                    pm = block_or_bits<NW>(pm, reinterpret_cast<int *>(red), wv, lane, red_slot);
                     PH(4);
                     bc = ground_bc();
                     PH(5);
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 const double a3 = fabs(i3);
                 if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf2 = 1;
             }
-            pf2 = block_or_bits<NW>(pf2, reinterpret_cast<int *>(red), wv, lane);
+            pf2 = block_or_bits<NW>(pf2, reinterpret_cast<int *>(red), wv, lane, red_slot);
             PH(6);
             if (!pf2) break;                                                         // SOS_OS.F:1585
         }
