@@ -249,12 +249,33 @@ __host__ __device__ constexpr int sos_ns(int nw, int rtwh) { return (sos_khm(nw,
 // the block come last, so the loads cannot be held back by possible aliasing), (2) the U independent coefficient /
 // source combinations run with full instruction-level parallelism, (3) only one FMA per level is on the dependent
 // chain.  DI = -1 sweeps from level nt down to 0 (up-going rows), DI = +1 from 0 to nt; all offsets are immediates.
-template <int DI, int U, int FS, int NS>
-__device__ __forceinline__ void scan_block(double *&q, const double *&qa, const double *&qd, double mu, double &z, double &sn)
+// O1 = true: the source is the single-scattering source of the direct beam (SOS_FSOURCE_ORDRE1, SOS_OS.F:2557-2559, with the
+// Fresnel-reflected beam of SOS_FSOURCE_DIFF_FRESNEL1 :3280-3289 when `fres`), formed on the fly from the per-level factors
+//   S1_i = sva (ch_i XDEL_i) + svr (ch_i YDEL_i) [+ sfa (fco_i XDEL_i) + sfr (fco_i YDEL_i)]
+// (lx -> ch XDEL at the level the ray has reached; the three other level vectors follow at multiples of lstr), instead of
+// being written to the field and read back.
+struct Order1 { double sva, svr, sfa, sfr; bool fres; };
+
+template <int DI, int U, int FS, int NS, bool O1>
+__device__ __forceinline__ void scan_block(double *&q, const double *&qa, const double *&qd, double mu, double &z, double &sn,
+                                           const double *&lx, int lstr, const Order1 &o1)
 {
     double av[U], sv[U], cv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = qa[DI * u * NS]; cv[u] = qd[DI * u]; sv[u] = q[DI * (u + 1) * FS]; }
+    for (int u = 0; u < U; ++u) { av[u] = qa[DI * u * NS]; cv[u] = qd[DI * u]; }
+    if (O1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) sv[u] = o1.sva * lx[DI * (u + 1)] + o1.svr * lx[lstr + DI * (u + 1)];
+        if (o1.fres) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                sv[u] = sv[u] + (o1.sfa * lx[2 * lstr + DI * (u + 1)] + o1.sfr * lx[3 * lstr + DI * (u + 1)]);
+        }
+        lx += DI * U;
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) sv[u] = q[DI * (u + 1) * FS];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const double omt = 1.0 - av[u];
@@ -391,29 +412,34 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
         // all field / attenuation / 1/dtau addresses as immediate offsets from three base registers.
         const double usign = (c == 2 && !up) ? -1. : 1.;     // U(-mu) is stored negated (see gemm_source)
         double xb = 0., xlo = 0., xhi = 0.;
-        auto scan_dir = [&](auto dir_tag, double bcv) {
+        Order1 o1 = {0., 0., 0., 0., false};
+        auto scan_dir = [&](auto dir_tag, auto o1_tag, double bcv) {
             constexpr int DI = decltype(dir_tag)::value;
+            constexpr bool O1 = decltype(o1_tag)::value;
             // q  -> field at the level the ray has reached, qa -> attenuation of the next layer, qd -> its 1/dtau
-            double *q = fld + (size_t)(DI < 0 ? nt : 0) * FS + rl;
+            const int i0 = DI < 0 ? nt : 0;
+            double *q = fld + (size_t)i0 * FS + rl;
             const double *qa = att + (size_t)(DI < 0 ? nt - 1 : 0) * NS + jj;
             const double *qd = idtau + (DI < 0 ? nt - 1 : 0);
+            const double *lx = cxd + i0;
             double z = bcv;
-            double sn = *q;                             // source at the level the ray comes from
+            // source at the level the ray comes from (no reflected-beam term there: SOS_OS.F:3280 excludes it)
+            double sn = O1 ? o1.sva * lx[0] + o1.svr * lx[LPB] : *q;
             *q = z;
             int k = 0;
 #pragma unroll 1
-            for (; k + 8 <= nt; k += 8) scan_block<DI, 8, FS, NS>(q, qa, qd, mu, z, sn);
-            if (nt & 4) scan_block<DI, 4, FS, NS>(q, qa, qd, mu, z, sn);
-            if (nt & 2) scan_block<DI, 2, FS, NS>(q, qa, qd, mu, z, sn);
-            if (nt & 1) scan_block<DI, 1, FS, NS>(q, qa, qd, mu, z, sn);
+            for (; k + 8 <= nt; k += 8) scan_block<DI, 8, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, LPB, o1);
+            if (nt & 4) scan_block<DI, 4, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, LPB, o1);
+            if (nt & 2) scan_block<DI, 2, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, LPB, o1);
+            if (nt & 1) scan_block<DI, 1, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, LPB, o1);
             xb = z;
         };
-        auto scan_row = [&](double bcv) {
+        auto scan_row = [&](auto o1_tag, double bcv) {
             if (up) {
-                if (active) scan_dir(std::integral_constant<int, -1>(), bcv);
+                if (active) scan_dir(std::integral_constant<int, -1>(), o1_tag, bcv);
             } else {
                 if (active) {
-                    scan_dir(std::integral_constant<int, 1>(), 0.);
+                    scan_dir(std::integral_constant<int, 1>(), o1_tag, 0.);
                     gnd[c * NS + jj] = xb * usign;
                 }
             }
@@ -464,32 +490,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 return v;
             };
 
-            // ---- scattering order 1: source (SOS_FSOURCE_ORDRE1) ---------------------------------
-            // S1_i = exp(-h_i/mus)/4 (sva XDEL_i + svr YDEL_i) [+ Fresnel-reflected beam term], SOS_OS.F:2557-2559,
-            // 3280-3289; the level factors are per-bin tables, the row factors carry the storage sign of U(-mu).
+            // ---- scattering order 1: row factors of the single-scattering source (SOS_FSOURCE_ORDRE1); the source itself
+            // is formed inside the first formal solution (scan_block<O1>); they carry the storage sign of U(-mu)
             const double *svp = cx.sv + (size_t)s * 4 * KP;
             if (active) {
-                const double sva = svp[rsv] * usign, svr = svp[KP + rsv] * usign;
-                double *q = fld + rl;
-                if (cx.ifresnel == 1) {
-                    const double sfa = svp[2 * KP + rsv] * usign, sfr = svp[3 * KP + rsv] * usign;
-#pragma unroll 1
-                    for (int i = 0; i <= nt; i++) {
-                        double v = sva * cxd[i] + svr * cyd[i];
-                        if (up ? (i < nt) : (i >= 1)) v = v + (sfa * fxd[i] + sfr * fyd[i]);
-                        q[(size_t)i * FS] = v;
-                    }
-                } else {
-                    int i = 0;
-#pragma unroll 1
-                    for (; i + 8 <= nt + 1; i += 8) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) q[u * FS] = sva * cxd[i + u] + svr * cyd[i + u];
-                        q += 8 * FS;
-                    }
-#pragma unroll 1
-                    for (; i <= nt; i++) { *q = sva * cxd[i] + svr * cyd[i]; q += FS; }
-                }
+                o1.sva = svp[rsv] * usign; o1.svr = svp[KP + rsv] * usign;
+                o1.fres = cx.ifresnel == 1;
+                if (o1.fres) { o1.sfa = svp[2 * KP + rsv] * usign; o1.sfr = svp[3 * KP + rsv] * usign; }
             }
             double bc = 0., dirterm = 0.;
             if (active && up) {                                                      // SOS_OS.F:970-992
@@ -516,7 +523,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             double i3lo = 0., dlo = 0., i3hi = 0., dhi = 0.;
             int ig = 1, iglast = 1;
             for (;;) {
-                scan_row(bc);                                                        // SOS_OS.F:1025 / 1244
+                if (ig == 1) scan_row(std::true_type(), bc);                         // SOS_OS.F:1025
+                else scan_row(std::false_type(), bc);                                // SOS_OS.F:1244
                 if (ig == 1) {                                                       // SOS_OS.F:1094-1137
                     __syncthreads();
                     PH(1);
