@@ -291,6 +291,30 @@ __device__ __forceinline__ void scan_block(double *&q, const double *&qa, const 
     q += DI * U * FS; qa += DI * U * NS; qd += DI * U;
 }
 
+// Down-going block of the field-in-HBM variant: the source of U consecutive levels is read from the LDS chunk the
+// contraction has just written (qs), the field goes straight to the scratch (q); same arithmetic as scan_block<+1>.
+template <int U, int FS, int NS>
+__device__ __forceinline__ void scan_block_split(double *&q, const double *&qs, const double *&qa, const double *&qd, double mu,
+                                                 double &z, double &sn)
+{
+    double av[U], sv[U], cv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { av[u] = qa[u * NS]; cv[u] = qd[u]; sv[u] = qs[u * FS]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double omt = 1.0 - av[u];
+        const double w = omt * (mu * cv[u]) - av[u];
+        const double pq = omt - w;
+        cv[u] = pq * sv[u] + w * (u ? sv[u - 1] : sn);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { z = z * av[u] + cv[u]; cv[u] = z; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u * FS] = cv[u];
+    sn = sv[U - 1];
+    q += U * FS; qs += U * FS; qa += U * NS; qd += U;
+}
+
 // NW   : waves per workgroup (4: N <= 42, 8: N <= 85); waves [0,NW/2) hold up-going rows, the rest down-going rows
 // RTWH : row tiles per wave and half system (tile = wave + rt*NW)
 // CT   : column tiles (16 levels each) held in LDS at once
@@ -435,9 +459,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             xb = z;
         };
         auto scan_row = [&](auto o1_tag, double bcv) {
+            constexpr bool O1 = decltype(o1_tag)::value;
             if (up) {
                 if (active) scan_dir(std::integral_constant<int, -1>(), o1_tag, bcv);
-            } else {
+            } else if (O1 || !BIG) {          // BIG, ig >= 2: the down sweep ran chunk by chunk inside the contraction loop
                 if (active) {
                     scan_dir(std::integral_constant<int, 1>(), o1_tag, 0.);
                     gnd[c * NS + jj] = xb * usign;
@@ -521,6 +546,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             // ---- scattering orders: formal solution of the current source, stop tests, next source ----------
             double i3 = 0., a1 = 0., d1 = 0., g1 = 0.;
             double i3lo = 0., dlo = 0., i3hi = 0., dhi = 0.;
+            double dn_z = 0., dn_s = 0.;           // BIG: running state of the chunk-wise down sweep
             int ig = 1, iglast = 1;
             for (;;) {
                 if (ig == 1) scan_row(std::true_type(), bc);                         // SOS_OS.F:1025
@@ -621,13 +647,45 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                         }
                     }
                     __syncthreads();
-                    if (BIG) {                                 // source chunk: LDS -> scratch
-                        for (int q = t; q < COLS * KH; q += NTH) {
-                            const int col = q / KH, r = q % KH;
-                            const int row = (r < KH / 2) ? 2 * r : KHM + 2 * r - KH;
-                            if (l0 + col <= nt)
-                                *reinterpret_cast<v2d *>(fld + (size_t)(l0 + col) * FS + row) =
-                                    *reinterpret_cast<const v2d *>(cbuf + (size_t)col * FS + row);
+                    if (BIG) {
+                        // Source chunk (levels l0..lv1) leaves LDS.  Up-going rows: S+ is copied to the scratch field (their
+                        // sweep runs from the ground upwards, after the last chunk).  Down-going rows: the chunks arrive in
+                        // the order of their sweep, so it runs here, straight from LDS -- S- never makes the round trip
+                        // through the scratch (a quarter of this variant's memory traffic).
+                        const int lv1 = min(l0 + COLS - 1, nt);
+                        if (active && up) {
+                            const double *qs = cbuf + rl;
+                            double *q = fld + (size_t)l0 * FS + rl;
+                            int lev = l0;
+#pragma unroll 1
+                            for (; lev + 8 <= lv1 + 1; lev += 8) {
+                                double v[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) v[u] = qs[u * FS];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) q[u * FS] = v[u];
+                                qs += 8 * FS; q += 8 * FS;
+                            }
+#pragma unroll 1
+                            for (; lev <= lv1; ++lev) { *q = *qs; qs += FS; q += FS; }
+                        } else if (active) {
+                            int start = l0;
+                            if (chk == 0) {                   // the ray enters at the top: X-(0) = 0, S-(0) is the first "previous" source
+                                dn_z = 0.; dn_s = cbuf[rl];
+                                fld[rl] = 0.;
+                                start = 1;
+                            }
+                            const double *qs = cbuf + (size_t)(start - l0) * FS + rl;
+                            double *q = fld + (size_t)start * FS + rl;
+                            const double *qa = att + (size_t)(start - 1) * NS + jj;
+                            const double *qd = idtau + (start - 1);
+                            int cnt = lv1 - start + 1;
+#pragma unroll 1
+                            for (; cnt >= 8; cnt -= 8) scan_block_split<8, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
+                            if (cnt & 4) scan_block_split<4, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
+                            if (cnt & 2) scan_block_split<2, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
+                            if (cnt & 1) scan_block_split<1, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
+                            if (lv1 == nt) { xb = dn_z; gnd[c * NS + jj] = xb * usign; }
                         }
                     }
                 }
