@@ -166,6 +166,19 @@ class SosContext:
                    "sosgpu_profile")
         return dict(nb=nb, lp=lp, perm=None, nt=nt, iborm=iborm, prof=prof, jout=jout, zz=zz, zprof=zprof, scal=scal)
 
+    def solve_band(self, bins, aik, seg=None, group=None):
+        """The whole per-wavelength bin loop of SOS_PROC (SOS_PROC.F:3459-3594) for bins already on the device
+        (upload_bins / make_profiles): fused SOS_OS of every bin, AIK-weighted SOS_AGGREGATE, and -- when
+        torch.distributed is initialised with more than one rank -- the one all-reduce that joins the ranks' bin
+        slices.  aik[nb]: this rank's normalised weights (in the order of `bins`; apply bins["perm"] first when the
+        upload was cost-sorted).  Returns (rec[nseg][smax+1][3][W] device tensor, scalars dict of dist.finish_scalars)."""
+        from . import dist as _dist
+        out = self.solve(bins)
+        rec, scal = self.aggregate(out, aik, seg=seg, scal=bins.get("scal"))
+        buf = _dist.all_reduce_partial(_dist.pack_partial(rec, scal), group=group)
+        rec, scal = _dist.unpack_partial(buf, rec.shape)
+        return rec, _dist.finish_scalars(scal)
+
     def alloc_outputs(self, nb):
         d = self.device
         return dict(rec=torch.empty((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),

@@ -157,8 +157,8 @@ def test_ckd_band_end_to_end(gpu_pkg, oracle):
     nb = len(aik)
     a_tr, piz, piztr = 0.3, 0.96, 0.94
     p = cx.make_profiles(nb, c["tr"], c["hr"], c["ta"], c["ha"], c["altabs"], tabs, a_tronc=a_tr, piz=piz, piztr=piztr)
-    out = cx.solve(p)
-    rec, sc = cx.aggregate(out, aik, scal=p["scal"])
+    rec, fin = cx.solve_band(p, aik)                                   # solve + aggregate (+ all-reduce when sharded)
+    out = cx.solve(p)                                                  # per-bin order counts for the comparison below
     torch.cuda.synchronize()
     assert int(p["nt"].min()) > 100
     W = 2 * len(mu) + 1
@@ -174,7 +174,6 @@ def test_ckd_band_end_to_end(gpu_pkg, oracle):
     exp_rec, exp_scal = oracle.aggregate(recs, nf, aik, sb)
     got = rec[0].cpu().numpy()
     cases.compare_records(got[:len(exp_rec)], exp_rec, 1e-9, "ckd band")
-    fin = gpu_pkg.dist.finish_scalars(sc)
     assert np.allclose([fin["emoins"][0], fin["eplus"][0]], exp_scal[1:3], rtol=1e-9)
     assert np.allclose([fin["ttot_tronc"][0], fin["ttot_vrai"][0]], exp_scal[3:5], rtol=1e-9)
     cx.close()
