@@ -8,6 +8,8 @@
  * Each entry point replaces one routine of the reference per-wavelength pipeline that
  * binding/run_sos.py reaches through sos.sos_proc (binding/run_sos.py:640, SOS_PROC.F:415):
  *
+ *   sosgpu_profile     <- SOS_PROFILE + SOS_DISC  src/SOS_PROFIL.F:224,1210 (+ the PROFIL read-back and rescale of
+ *                                                 SOS, src/SOS.F:511-550; all bins of a wavelength at once)
  *   sosgpu_noyaux      <- SOS_NOYAUX              src/SOS_OS.F:1857   (phase-matrix Fourier kernels,
  *                                                                     hoisted out of the bin loop)
  *   sosgpu_os_solve    <- SOS_OS (+ leaves)       src/SOS_OS.F:303    (one call = a batch of CKD bins,
