@@ -177,3 +177,39 @@ def test_ckd_band_end_to_end(gpu_pkg, oracle):
     assert np.allclose([fin["emoins"][0], fin["eplus"][0]], exp_scal[1:3], rtol=1e-9)
     assert np.allclose([fin["ttot_tronc"][0], fin["ttot_vrai"][0]], exp_scal[3:5], rtol=1e-9)
     cx.close()
+
+
+@pytest.mark.gpu
+def test_device_profile_random_columns(gpu_pkg, oracle):
+    """Many random gas columns in one batch against the restatement: NT and the level altitudes identical, H / XDEL / YDEL
+    to the last printed digit.  (SOS_FUZZ_N bins, default 48.)"""
+    import torch
+    nb = int(os.environ.get("SOS_FUZZ_N", "48"))
+    rng = np.random.default_rng(11)
+    alt = np.concatenate([np.linspace(120.0, 30.0, 10), np.linspace(28.0, 0.0, 40)])
+    tr, hr, ta, ha = 0.06, 8.2, 0.22, 2.4
+    tabs = np.zeros((nb, 50))
+    for b in range(nb):
+        hg = rng.uniform(1.5, 9.0)
+        col = np.exp(-alt / hg) * np.exp(rng.uniform(np.log(1e-4), np.log(40.0)))
+        col = np.maximum.accumulate(col * (1.0 + 0.05 * rng.random(50)))      # monotone, slightly irregular
+        col[0] = 0.0
+        tabs[b] = col
+    cx = _ctx(gpu_pkg)
+    p = cx.make_profiles(nb, tr, hr, ta, ha, alt, tabs)
+    torch.cuda.synchronize()
+    nt = p["nt"].cpu().numpy(); prof = p["prof"].cpu().numpy(); z = p["zprof"].cpu().numpy()
+    exact = 0
+    for b in range(nb):
+        r = oracle.sos_profile(tr, hr, ta, ha, alt, tabs[b])
+        if r["ier"] != 0:
+            assert nt[b] == -1
+            continue
+        assert nt[b] == r["nt"], (b, nt[b], r["nt"])
+        k = r["nt"] + 1
+        assert np.array_equal(z[b, :k], r["zprof"]), b
+        for row, key in enumerate(("h", "xdel", "ydel")):
+            assert np.allclose(prof[b, row, :k], r[key], rtol=2e-8, atol=1e-300), (b, key)
+        exact += int(all(np.array_equal(prof[b, row, :k], r[key]) for row, key in enumerate(("h", "xdel", "ydel"))))
+    print("bit-identical bins: %d/%d" % (exact, nb))
+    cx.close()
