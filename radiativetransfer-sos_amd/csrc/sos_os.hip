@@ -322,13 +322,15 @@ __device__ __forceinline__ void scan_block_split(double *&q, const double *&qs, 
 // BIG = true : the field, the attenuation table and the level vectors live in a per-bin HBM/L2 scratch
 //              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of
 //              16*CT levels staged through LDS, the formal solution streams the scratch.
+// SURF = true: BRDF/BPDF reflection matrices (IMAT_SURF = 1, SOS_OS.F:912-925); a template argument because its per-row
+//             matrix pointers and direct-beam terms otherwise stay live across the contraction (30 spilled VGPRs, -2.6 %)
 // ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- two extra levels per row are
 //             read back from the field after every formal solution.
 // Register bound: 256 architectural VGPRs (two workgroups per CU for NW = 4 when the LDS allows it).  The 512-register
 // form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded form with a few
 // scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one instantiation gave wrong down-going rows on
 // gfx950, so it is not used.
-template <int NW, int RTWH, int CT, bool BIG, bool ZO>
+template <int NW, int RTWH, int CT, bool BIG, bool ZO, bool SURF>
 __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
@@ -423,12 +425,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
         }
         // bin-constant exponentials of the ground boundary terms (SOS_OS.F:979,985,1068-1077)
         const double e_sun = uniform_f64(exp(-htot / cx.mus));
-        double e_mu = 0., e_lo = 0., e_hi = 0.;
-        if (cx.imat_surf && active && up) {
-            e_mu = exp(-htot / mu);
-            e_lo = exp(-(htot - h0) / mu);        // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
-            if (ZO && jout) { e_lo = exp(-(htot - hlo) / mu); e_hi = exp(-(htot - hhi) / mu); }
-        }
         __syncthreads();
 
         // per-thread formal solution of its row, in place over the source held in fld.  bcv = value at the ground for
@@ -481,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
         PH_T0();
         for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
             sign = -sign;
-            const float *rs = cx.imat_surf ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
+            const float *rs = SURF ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
             // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239)
             auto ground_bc = [&]() -> double {
                 if (!(active && up)) return 0.;
@@ -493,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     lsol = 2 * lsol * cx.ro;
                     v = lsol; xr = lsol;
                 }
-                if (cx.imat_surf) {
+                if (SURF) {
                     double acc2 = 0.;
                     const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + (size_t)jj * N;
                     const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + (size_t)jj * N;
@@ -523,24 +519,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 o1.fres = cx.ifresnel == 1;
                 if (o1.fres) { o1.sfa = svp[2 * KP + rsv] * usign; o1.sfr = svp[3 * KP + rsv] * usign; }
             }
-            double bc = 0., dirterm = 0.;
-            if (active && up) {                                                      // SOS_OS.F:970-992
-                double xr = 0.;
-                if (c == 0 && cx.ro != 0. && s == 0) { bc = cx.ro * cx.mus * e_sun; xr = bc; }
-                if (cx.imat_surf) {
+            // direct solar beam reflected by the surface into this (up-going) row: Lambert part xr, BRDF/BPDF part
+            // dirterm = R_a1(N0,k) exp(-tau/mus)/mu_k (SOS_OS.F:970-992).  Evaluated again at the end of the order
+            // instead of being kept in registers across the scattering orders.
+            auto direct_beam = [&](double &xr) -> double {
+                double v = 0.;
+                xr = 0.;
+                if (c == 0 && cx.ro != 0. && s == 0) { v = cx.ro * cx.mus * e_sun; xr = v; }
+                if (SURF) {
                     const double rr = e_sun / mu;
                     double r = rs[(size_t)(c * 3) * N * N + (size_t)jj * N + (cx.n0 - 1)];
                     if (!cx.ipolar && c) r = 0.;
-                    bc = bc + r * rr;
-                    dirterm = bc - xr;                                               // SOS_OS.F:1070-1072
+                    v = v + r * rr;
                 }
-            }
-            double rii = 0., riilo = 0., riihi = 0.;
-            if (cx.imat_surf && active && up) {                                      // SOS_OS.F:1062-1084
-                rii = e_mu * dirterm;
-                riilo = e_lo * dirterm;
-                if (ZO) riihi = e_hi * dirterm;
-            }
+                return v;
+            };
+            double bc = 0.;
+            if (active && up) { double xr; bc = direct_beam(xr); }
             PH(0);
 
             // ---- scattering orders: formal solution of the current source, stop tests, next source ----------
@@ -695,9 +690,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             // SOS_OS.F:1421-1439.  The record is built from I3OUT (minus RIIOUT at the output level), the stop
             // tests and fluxes from I3 (minus RII): the two differ by exp(H(0)/mu) on the direct term.
             double i3out0 = i3;
-            if (cx.imat_surf && active && up) {
+            if (SURF && active && up) {                                      // SOS_OS.F:1062-1084
+                double xr;
+                const double b0 = direct_beam(xr);
+                const double dirterm = b0 - xr;                                      // SOS_OS.F:1070-1072
+                const double rii = exp(-htot / mu) * dirterm;
+                // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
+                const double riilo = exp(-(htot - ((ZO && jout) ? hlo : h0)) / mu) * dirterm;
                 i3out0 = i3 - riilo; i3 = i3 - rii;
-                if (ZO) { i3lo = i3lo - riilo; i3hi = i3hi - riihi; }
+                if (ZO) {
+                    const double riihi = (jout ? exp(-(htot - hhi) / mu) : 0.) * dirterm;
+                    i3lo = i3lo - riilo; i3hi = i3hi - riihi;
+                }
             }
 
             if (s == 0) {                                                            // SOS_OS.F:1447-1456
@@ -792,10 +796,10 @@ size_t sos_os_scratch_doubles(int n, int lpb)
     return (size_t)lpb * (sos_fs(w, r) + sos_ns(w, r) + 7);
 }
 
-template <int NW, int RTWH, int CT, bool BIG, bool ZO>
+template <int NW, int RTWH, int CT, bool BIG, bool ZO, bool SURF>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
 {
-    auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO>;
+    auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO, SURF>;
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif
@@ -819,8 +823,13 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     if (big && (!bn.scratch || bn.lpb < nt_max + 1)) return SOSGPU_E_UNSUPPORTED;
     const int zo = bn.jout != nullptr;
 #define V(NWV, R, C, B)                                                                   \
-    if (nw == NWV && rtw == R && ct == C && big == B)                                     \
-        return zo ? launch_variant<NWV, R, C, B, true>(cx, bn, lds, st) : launch_variant<NWV, R, C, B, false>(cx, bn, lds, st);
+    if (nw == NWV && rtw == R && ct == C && big == B) {                                   \
+        if (cx.imat_surf)                                                                 \
+            return zo ? launch_variant<NWV, R, C, B, true, true>(cx, bn, lds, st)         \
+                      : launch_variant<NWV, R, C, B, false, true>(cx, bn, lds, st);       \
+        return zo ? launch_variant<NWV, R, C, B, true, false>(cx, bn, lds, st)            \
+                  : launch_variant<NWV, R, C, B, false, false>(cx, bn, lds, st);          \
+    }
     V(4, 1, 2, 0) V(4, 2, 2, 0) V(8, 2, 2, 0)
     V(4, 1, 4, 0) V(8, 1, 4, 0)
     V(4, 1, 2, 1) V(4, 2, 2, 1) V(8, 2, 2, 1)
