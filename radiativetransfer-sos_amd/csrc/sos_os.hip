@@ -115,7 +115,7 @@ __device__ __forceinline__ double queue_term(double d, double g)
 // before the 16+ MFMAs of k-pair m are issued (two register sets each, used alternately, no copies), so neither the
 // L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection rides in the same loop (RAY = half
 // system it acts on, -1 = none): 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
-template <int NA, int RAY, int RTWH, int CT, int NW, int FS, int KHM>
+template <int NA, int RAY, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B>
 __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
                                             const double *__restrict__ vt, const double *__restrict__ uf,
                                             int ks2h, int rtph, const double *bx, const double *xdel,
@@ -175,17 +175,31 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
         AFrag f0, f1;
         BRaw b0, b1;
         load_a(f0, 0);
-        load_b(b0, 0);
         int m = 0;
+        if (PIPE_B) {
+            load_b(b0, 0);
 #pragma unroll 1
-        for (; m + 1 < ks2h; m += 2) {
-            load_a(f1, m + 1);
-            load_b(b1, m + 1);
-            mma(f0, b0);
-            if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
-            mma(f1, b1);
+            for (; m + 1 < ks2h; m += 2) {
+                load_a(f1, m + 1);
+                load_b(b1, m + 1);
+                mma(f0, b0);
+                if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
+                mma(f1, b1);
+            }
+            if (m < ks2h) mma(f0, b0);
+        } else {
+            // four column tiles: one set of B registers (32 VGPRs) -- the second set costs more in spills than it hides
+#pragma unroll 1
+            for (; m + 1 < ks2h; m += 2) {
+                load_a(f1, m + 1);
+                load_b(b0, m);
+                mma(f0, b0);
+                if (m + 2 < ks2h) load_a(f0, m + 2);
+                load_b(b0, m + 1);
+                mma(f1, b0);
+            }
+            if (m < ks2h) { load_b(b0, m); mma(f0, b0); }
         }
-        if (m < ks2h) mma(f0, b0);
         // XDEL of the output level: every accumulator register of a lane belongs to one column
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
@@ -607,13 +621,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     auto contract = [&](auto na_tag) {
                         constexpr int NA = decltype(na_tag)::value;
                         if (s > 2)
-                            gemm_source<NA, -1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
+                            gemm_source<NA, -1, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
                                                                        xdel + l0, ydel + l0, lane, wv);
                         else if (s & 1)
-                            gemm_source<NA, 1, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
+                            gemm_source<NA, 1, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
                                                                       xdel + l0, ydel + l0, lane, wv);
                         else
-                            gemm_source<NA, 0, RTWH, CT, NW, FS, KHM>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
+                            gemm_source<NA, 0, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
                                                                       xdel + l0, ydel + l0, lane, wv);
                     };
                     if (tile_b) contract(std::integral_constant<int, RTWH>());
