@@ -48,6 +48,8 @@ class SosContext:
         self.mu = np.ascontiguousarray(mu, dtype=np.float64)
         self.ga = np.ascontiguousarray(ga, dtype=np.float64)
         coefs = [np.ascontiguousarray(x, dtype=np.float64) for x in (alpha, beta, gamma, zeta)]
+        self._coefs = coefs
+        self._opts = dict(ind_surf=float(ind_surf), ron=float(ron), ipolar=int(ipolar), igmax=int(igmax))
         for x in coefs:
             if len(x) != self.os_nb + 1:
                 raise ValueError("alpha/beta/gamma/zeta must all have os_nb+1 entries")
@@ -178,6 +180,31 @@ class SosContext:
         buf = _dist.all_reduce_partial(_dist.pack_partial(rec, scal), group=group)
         rec, scal = _dist.unpack_partial(buf, rec.shape)
         return rec, _dist.finish_scalars(scal)
+
+    def diffuse_transmissions(self, bins):
+        """Diffuse transmissions of the `-SOS.Trans` option (SOS.F:600-635): for the solar direction and for every
+        direction J as incidence, SOS_OS restricted to Fourier order 0 over a black, non-reflecting ground
+        (RHO = 0, IMAT_SURF = IFRESNEL = 0, IBORM = 0, ZOUT = -1); its EMOINS is TDIFMUS (N0 = solar index) resp.
+        TDIFMUG(J) (N0 = J).  One order-0 context per incidence direction (they differ in the single-scattering
+        vectors only), all bins per launch.  Returns (tdifmus[nb], tdifmug[nb][N]) as device tensors; values are for
+        the equivalent (truncated) atmosphere, as SOS_OS delivers them."""
+        nb = bins["nb"]
+        zeros = torch.zeros(nb, dtype=torch.int32, device=self.device)
+        sub = dict(bins, iborm=zeros, jout=None, zz=None)
+        tdifmug = torch.empty((nb, self.n), dtype=torch.float64, device=self.device)
+        tdifmus = None
+        for j in range(1, self.n + 1):
+            cx = SosContext(self.mu, self.ga, j, *self._coefs, iborm_max=0, ro=0.0, imat_surf=0, ifresnel=0,
+                            device=self.device, **self._opts)
+            try:
+                out = cx.solve(sub)
+                tdifmug[:, j - 1] = out["flux"][:, 0]
+                if j == self.n0:
+                    tdifmus = out["flux"][:, 0].clone()
+                torch.cuda.synchronize(self.device)
+            finally:
+                cx.close()
+        return tdifmus, tdifmug
 
     def alloc_outputs(self, nb):
         d = self.device

@@ -137,3 +137,28 @@ def test_malformed_bin_is_flagged_not_faulted(gpu_pkg):
     torch.cuda.synchronize()
     assert int(out["norders"][1]) == -1 and int(out["norders"][0]) > 0
     cx.close()
+
+
+def test_diffuse_transmissions_vs_oracle(gpu_pkg, oracle):
+    """-SOS.Trans (SOS.F:600-635): order-0, black-ground solves with every direction as incidence."""
+    import torch
+    S = gpu_pkg.synth
+    mu, w, n0 = S.gauss_angles(8, 35.0)
+    os_nb = 16
+    al, be, ga, ze = S.hg_phase(os_nb, 0.6)
+    cx = gpu_pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=os_nb, ro=0.2)
+    hs, xs, ys = [], [], []
+    for k in (0.0, 0.8):
+        h, x, y, z = S.profile(20, k_abs=k)
+        h, x, y, ib = S.rescale_profile(h, x, y, 0.3, 0.95, 0.93, os_nb)
+        hs.append(h); xs.append(x); ys.append(y)
+    bins = cx.upload_bins(np.array(hs), np.array(xs), np.array(ys))
+    tdifmus, tdifmug = cx.diffuse_transmissions(bins)
+    torch.cuda.synchronize()
+    tdifmus, tdifmug = tdifmus.cpu().numpy(), tdifmug.cpu().numpy()
+    for b in range(2):
+        for j in range(1, len(mu) + 1):
+            r = oracle.sos_os(mu, w, os_nb, hs[b], xs[b], ys[b], al, be, ga, ze, n0=j, ro=0.0, iborm=0)
+            assert abs(tdifmug[b, j - 1] - r["emoins"]) <= 1e-9 * abs(r["emoins"]) + 1e-300, (b, j)
+        assert tdifmus[b] == tdifmug[b, n0 - 1]
+    cx.close()
