@@ -110,7 +110,7 @@ __device__ __forceinline__ double queue_term(double d, double g)
 // plus, for s <= 2, the molecular operator in its exact rank-4 form on the one half system it acts on:
 //   acc[sr] += U (YDEL o (V^T X^sr))                                             (noyaux.hip k_pack_ray)
 // A wave works on NA (1 or 2) row tiles tile0, tile0 + NW of BOTH systems x CT column tiles; bx = its B-fragment
-// base (column lane&15, k-quad lane>>4) in the LDS field/staging buffer with level stride FS.
+// base (column lane&15, k-quad lane>>4) in the field (LDS, or the HBM scratch of the BIG variants) with level stride FS.
 // Software pipeline: the A fragments (global/L2) and the raw B operands X+, X- (LDS) of k-pair m+1 are requested
 // before the 16+ MFMAs of k-pair m are issued (two register sets each, used alternately, no copies), so neither the
 // L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection rides in the same loop (RAY = half
@@ -334,8 +334,9 @@ __device__ __forceinline__ void scan_block_split(double *&q, const double *&qs, 
 // CT   : column tiles (16 levels each) held in LDS at once
 // BIG = false: the whole field (NT+1 <= 16*CT levels) lives in LDS.
 // BIG = true : the field, the attenuation table and the level vectors live in a per-bin HBM/L2 scratch
-//              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of
-//              16*CT levels staged through LDS, the formal solution streams the scratch.
+//              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of 16*CT levels
+//              reading its B operands from the scratch, the source chunk lands in LDS: the down-going rows are swept from
+//              it right away, S+ is copied out and the up-going rows are swept after the last chunk.
 // SURF = true: BRDF/BPDF reflection matrices (IMAT_SURF = 1, SOS_OS.F:912-925); a template argument because its per-row
 //             matrix pointers and direct-beam terms otherwise stay live across the contraction (30 spilled VGPRs, -2.6 %)
 // ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- two extra levels per row are
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
     constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
     const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
     const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
-    double *cbuf = smem;                   // [COLS][FS]  LDS: the field itself, or the staging chunk (BIG)
+    double *cbuf = smem;                   // [COLS][FS]  LDS: the field itself, or the source chunk (BIG)
     double *gnd = cbuf + COLS * FS;        // [3][NS] down-going field at the ground, order ig-1
     double *i3s = gnd + 3 * NS;            // [2][NS] I3 of the I rows (flux integrals)
     double *red = i3s + 2 * NS;            // [16]
