@@ -70,8 +70,9 @@ int  sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv, const do
 int  sosgpu_destroy(sosgpu_ctx *cx);
 
 /* Surface reflection matrices for imat_surf=1: REAL*4, reference FICSURF record order
- * d_rsurf[s][ab][(J-1)*N+(I-1)] = R_ab(I,J), s = 0..iborm_max (SOS_OS.F:916-925).  Device pointer,
- * borrowed (must stay valid until the last solve). */
+ * d_rsurf[s][ab][(J-1)*N+(I-1)] = R_ab(I,J), s = 0..iborm_max (SOS_OS.F:916-925).  Device pointer; the call
+ * copies the matrices into the context (transposed, so that the rows k of a wavefront read consecutive floats) and
+ * synchronises the device -- the caller may release d_rsurf afterwards. */
 int  sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf);
 
 /* Replaces SOS_NOYAUX (SOS_OS.F:1857-2158) for every Fourier order 0..iborm_max at once; must be called

@@ -34,6 +34,7 @@ struct sosgpu_ctx {
     double *agg_partial;    // chunk partials of the large-batch aggregate
     double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
     double *prof_ng;        // [4][608] no-gas profile of the wavelength (sosgpu_profile)
+    float *rsurf_t;         // transposed copy of the caller's surface matrices (context-owned)
     size_t scratch_doubles;
 };
 
@@ -96,6 +97,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->phase = nullptr;
     cx->agg_partial = nullptr;
     cx->prof_ng = nullptr;
+    cx->rsurf_t = nullptr;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -207,11 +209,32 @@ extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
 
 extern "C" size_t sosgpu_ctx_bytes(const sosgpu_ctx *cx) { return cx ? cx->bytes : 0; }
 
+// rt[s][ab][j][k] = r[s][ab][k][j]: the solver reads, for an up-going row k, the matrix column over the incident
+// directions j -- with the transposed copy consecutive lanes (rows k) read consecutive floats.
+__global__ void k_transpose_surface(int n, size_t nmat, const float *__restrict__ r, float *__restrict__ rt)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nmat * n * n) return;
+    const size_t mat = e / ((size_t)n * n);
+    const int j = (int)((e / n) % n), k = (int)(e % n);
+    rt[e] = r[mat * n * n + (size_t)k * n + j];
+}
+
 extern "C" int sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf)
 {
     if (!cx) return SOSGPU_E_ARG;
     if (cx->d.imat_surf && !d_rsurf) return SOSGPU_E_ARG;
-    cx->d.rsurf = d_rsurf;
+    if (!d_rsurf) { cx->d.rsurf = nullptr; return SOSGPU_OK; }
+    HIPCHK(hipSetDevice(cx->device));
+    const size_t nmat = (size_t)(cx->d.smax + 1) * 9, cnt = nmat * cx->d.n * cx->d.n;
+    if (!cx->rsurf_t) {
+        int rc = dev_alloc(cx, &cx->rsurf_t, cnt);
+        if (rc) return rc;
+    }
+    k_transpose_surface<<<(unsigned)((cnt + 255) / 256), 256>>>(cx->d.n, nmat, d_rsurf, cx->rsurf_t);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());          // the caller may release or overwrite d_rsurf afterwards
+    cx->d.rsurf = cx->rsurf_t;
     return SOSGPU_OK;
 }
 

@@ -47,7 +47,7 @@ struct SosDev {                 // per-wavelength device context, passed by valu
     double *mp_vt;              // [3][ks2h*128]  molecular operator, projection factor V^T (one 16-row tile, rows 0..3 used)
     double *mp_uf;              // [3][rtph*64]   molecular operator, expansion factor U (K = 4)
     double *sv;                 // [smax+1][4][kp]: order-1 vectors aer, ray, fresnel-aer, fresnel-ray
-    const float *rsurf;         // [smax+1][9][N][N] or null
+    const float *rsurf;         // [smax+1][9][N j][N k] TRANSPOSED surface matrices R_ab(k <- j) (api.hip), or null
 };
 
 struct SosBins {

@@ -505,15 +505,32 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     v = lsol; xr = lsol;
                 }
                 if (SURF) {
+                    // 3 x 3 block product with the REAL*4 matrices (SOS_OS.F:1194-1220); rs is transposed, so the lanes of a
+                    // wave (rows k) read consecutive floats and the j loop can run several loads ahead
                     double acc2 = 0.;
-                    const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + (size_t)jj * N;
-                    const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + (size_t)jj * N;
-                    const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + (size_t)jj * N;
+                    const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + jj;
+                    const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + jj;
+                    const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + jj;
+                    const bool pol = cx.ipolar != 0;
 #pragma unroll 1
-                    for (int j = 0; j < N; j++) {
-                        double q0 = r0[j], q1 = r1[j], q2 = r2[j];
-                        if (!cx.ipolar) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }   // SOS_OS.F:928-941
-                        acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[NS + j] * q1 + gnd[2 * NS + j] * q2);
+                    for (int j0 = 0; j0 < N; j0 += 16) {
+                        // 48 independent loads in flight per batch of 16 incident directions (the matrices sit in L2: one
+                        // round trip per batch instead of one per direction)
+                        float f0[16], f1[16], f2[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const size_t o = (size_t)min(j0 + u, N - 1) * N;
+                            f0[u] = r0[o]; f1[u] = r1[o]; f2[u] = r2[o];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const int j = j0 + u;
+                            if (j < N) {
+                                double q0 = f0[u], q1 = f1[u], q2 = f2[u];
+                                if (!pol) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }    // SOS_OS.F:928-941
+                                acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[NS + j] * q1 + gnd[2 * NS + j] * q2);
+                            }
+                        }
                     }
                     v = acc2 * (2 / mu) + xr;
                 }
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 if (c == 0 && cx.ro != 0. && s == 0) { v = cx.ro * cx.mus * e_sun; xr = v; }
                 if (SURF) {
                     const double rr = e_sun / mu;
-                    double r = rs[(size_t)(c * 3) * N * N + (size_t)jj * N + (cx.n0 - 1)];
+                    double r = rs[(size_t)(c * 3) * N * N + (size_t)(cx.n0 - 1) * N + jj];
                     if (!cx.ipolar && c) r = 0.;
                     v = v + r * rr;
                 }
