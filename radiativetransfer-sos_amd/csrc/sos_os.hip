@@ -552,8 +552,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 if (o1.fres) { o1.sfa = svp[2 * KP + rsv] * usign; o1.sfr = svp[3 * KP + rsv] * usign; }
             }
             // direct solar beam reflected by the surface into this (up-going) row: Lambert part xr, BRDF/BPDF part
-            // dirterm = R_a1(N0,k) exp(-tau/mus)/mu_k (SOS_OS.F:970-992).  Evaluated again at the end of the order
-            // instead of being kept in registers across the scattering orders.
+            // dirterm = R_a1(N0,k) exp(-tau/mus)/mu_k (SOS_OS.F:970-992)
             auto direct_beam = [&](double &xr) -> double {
                 double v = 0.;
                 xr = 0.;
@@ -566,8 +565,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 }
                 return v;
             };
-            double bc = 0.;
-            if (active && up) { double xr; bc = direct_beam(xr); }
+            double bc = 0., dirterm = 0.;          // dirterm is only kept (SURF variants) for the end of the order
+            if (active && up) { double xr; bc = direct_beam(xr); if (SURF) dirterm = bc - xr; }  // SOS_OS.F:1070-1072
             PH(0);
 
             // ---- scattering orders: formal solution of the current source, stop tests, next source ----------
@@ -723,9 +722,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             // tests and fluxes from I3 (minus RII): the two differ by exp(H(0)/mu) on the direct term.
             double i3out0 = i3;
             if (SURF && active && up) {                                      // SOS_OS.F:1062-1084
-                double xr;
-                const double b0 = direct_beam(xr);
-                const double dirterm = b0 - xr;                                      // SOS_OS.F:1070-1072
                 const double rii = exp(-htot / mu) * dirterm;
                 // standard output: RIIOUT(0,K), SOS_OS.F:1068 (H(0) != 0)
                 const double riilo = exp(-(htot - ((ZO && jout) ? hlo : h0)) / mu) * dirterm;
