@@ -512,18 +512,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + jj;
                     const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + jj;
                     const bool pol = cx.ipolar != 0;
+                    constexpr int SB = 24;          // N = 41: two batches
 #pragma unroll 1
-                    for (int j0 = 0; j0 < N; j0 += 16) {
-                        // 48 independent loads in flight per batch of 16 incident directions (the matrices sit in L2: one
+                    for (int j0 = 0; j0 < N; j0 += SB) {
+                        // 3 SB independent loads in flight per batch of SB incident directions (the matrices sit in L2: one
                         // round trip per batch instead of one per direction)
-                        float f0[16], f1[16], f2[16];
+                        float f0[SB], f1[SB], f2[SB];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
+                        for (int u = 0; u < SB; ++u) {
                             const size_t o = (size_t)min(j0 + u, N - 1) * N;
                             f0[u] = r0[o]; f1[u] = r1[o]; f2[u] = r2[o];
                         }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
+                        for (int u = 0; u < SB; ++u) {
                             const int j = j0 + u;
                             if (j < N) {
                                 double q0 = f0[u], q1 = f1[u], q2 = f2[u];
