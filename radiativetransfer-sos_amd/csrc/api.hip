@@ -110,6 +110,10 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     for (int j = 0; j < N; j++) nwgt += ga[j] != 0.0;
     if (nwgt < 1) { delete cx; return SOSGPU_E_ARG; }
     d.ks2h = (3 * nwgt + 7) / 8;
+    {   // projection rows ride in the last quad of the last row tile when that quad is padding
+        const int cand = ((3 * N - 1) / 16) * 16 + 12;
+        d.prow = cand >= 3 * N ? cand : -1;
+    }
     std::vector<int32_t> rowmap(d.kh, -1);
     {
         int pos = 0;

@@ -163,6 +163,25 @@ __device__ inline double half_element(const SosDev &cx, int s, int sys, int row,
     return 0.25 * cx.ga[j - 1] * v;
 }
 
+// Element (row 0..3, half-system position col) of the projection factor V^T of the molecular operator (see k_pack_ray)
+__device__ inline double ray_vt_element(const SosDev &cx, int s, int row, int col)
+{
+    const int N = cx.n, W = cx.w, B = cx.os_nb;
+    const double *P = cx.prt + ((size_t)(s * 3 + 0) * (B + 1) + 2) * W + N;   // l = 2
+    const double *R = cx.prt + ((size_t)(s * 3 + 1) * (B + 1) + 2) * W + N;
+    const double *T = cx.prt + ((size_t)(s * 3 + 2) * (B + 1) + 2) * W + N;
+    const double b0 = (s == 0) ? 1. : 0., b2 = cx.beta2, g2 = cx.gamma2, a2 = cx.alpha2;
+    const int cl = cx.rowmap[col];
+    const int ci = cl / N, j = cl % N + 1;
+    const double hw = 0.5 * cx.ga[j - 1];
+    const double f = (ci == 0) ? P[j] : (ci == 1 ? R[j] : T[j]);
+    const double c0[3] = {b2, g2, -g2}, c1[3] = {g2, a2, -a2}, c2[3] = {-g2, -a2, a2};
+    if (row == 0) return hw * c0[ci] * f;
+    if (row == 1) return hw * c1[ci] * f;
+    if (row == 2) return hw * c2[ci] * f;
+    return (ci == 0) ? hw * b0 : 0.;
+}
+
 __global__ void k_pack(SosDev cx)
 {
     const int s = blockIdx.y;
@@ -177,7 +196,12 @@ __global__ void k_pack(SosDev cx)
     const int col = 8 * m + 2 * (lane >> 4) + e2;
     const int H = 3 * cx.n;
     const bool in = row < H && col < H;
-    cx.mp_aer[(size_t)s * 2 * per + e] = in ? half_element<false>(cx, s, sys, row, col) : 0.;
+    double v = in ? half_element<false>(cx, s, sys, row, col) : 0.;
+    // the four projection rows of the rank-4 molecular operator ride in padding rows of the half system they act on
+    // (A for even s, B for odd s): the dense contraction then delivers V^T X for free
+    if (cx.prow >= 0 && s <= 2 && sys == (s & 1) && row >= cx.prow && row < cx.prow + 4 && col < H)
+        v = ray_vt_element(cx, s, row - cx.prow, col);
+    cx.mp_aer[(size_t)s * 2 * per + e] = v;
 }
 
 // Molecular (Rayleigh) part of the source operator for s <= 2 (SOS_OS.F:2859-2876).  Its kernels are single
@@ -198,24 +222,12 @@ __global__ void k_pack_ray(SosDev cx)
     const double *P = cx.prt + ((size_t)(s * 3 + 0) * (B + 1) + 2) * W + N;   // l = 2
     const double *R = cx.prt + ((size_t)(s * 3 + 1) * (B + 1) + 2) * W + N;
     const double *T = cx.prt + ((size_t)(s * 3 + 2) * (B + 1) + 2) * W + N;
-    const double b0 = (s == 0) ? 1. : 0., b2 = cx.beta2, g2 = cx.gamma2, a2 = cx.alpha2;
     double *vt = cx.mp_vt + (size_t)s * cx.ks2h * 128;
     double *uf = cx.mp_uf + (size_t)s * cx.rtph * 64;
     for (int e = threadIdx.x; e < cx.ks2h * 128; e += blockDim.x) {
         const int e2 = e & 1, lane = (e >> 1) & 63, m = e >> 7;
         const int row = lane & 15, col = 8 * m + 2 * (lane >> 4) + e2;
-        double v = 0.;
-        if (row < 4 && col < 3 * N) {
-            const int cl = cx.rowmap[col];
-            const int ci = cl / N, j = cl % N + 1;
-            const double hw = 0.5 * cx.ga[j - 1];
-            const double f = (ci == 0) ? P[j] : (ci == 1 ? R[j] : T[j]);
-            const double c0[3] = {b2, g2, -g2}, c1[3] = {g2, a2, -a2}, c2[3] = {-g2, -a2, a2};
-            if (row == 0) v = hw * c0[ci] * f;
-            else if (row == 1) v = hw * c1[ci] * f;
-            else if (row == 2) v = hw * c2[ci] * f;
-            else v = (ci == 0) ? hw * b0 : 0.;
-        }
+        const double v = (row < 4 && col < 3 * N) ? ray_vt_element(cx, s, row, col) : 0.;
         vt[e] = v;
     }
     for (int e = threadIdx.x; e < cx.rtph * 64; e += blockDim.x) {

@@ -31,6 +31,8 @@ struct SosDev {                 // per-wavelength device context, passed by valu
     int kp;                     // order-1 vector stride (6N padded to 8)
     int kh, ks2h, rtph;         // half system: rows 3N padded to 8; k-pairs of the contraction ceil(3 Nw / 8); 16-row tiles ceil(kh/16)
     int nwgt;                   // Nw: directions with a non-zero quadrature weight
+    int prow;                   // first of four PADDING rows (>= 3N, same 16-row tile as row 3N-1, multiple of 4) that carry the
+                                // rank-4 projection V^T of the molecular operator in the packed A operand, or -1
     const int32_t *rowmap;      // [kh] half-system position -> c*N + (k-1) (weighted directions first), -1 = padding
     int os_nb, smax;            // OS_NB, iborm_max
     int n0, imat_surf, ifresnel, igmax, ipolar;

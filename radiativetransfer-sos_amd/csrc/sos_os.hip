@@ -115,12 +115,16 @@ __device__ __forceinline__ double queue_term(double d, double g)
 // before the 16+ MFMAs of k-pair m are issued (two register sets each, used alternately, no copies), so neither the
 // L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection rides in the same loop (RAY = half
 // system it acts on, -1 = none): 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
-template <int NA, int RAY, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B>
+template <int NA, int RAY, bool FOLD, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B>
 __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
                                             const double *__restrict__ vt, const double *__restrict__ uf,
                                             int ks2h, int rtph, const double *bx, const double *xdel,
-                                            const double *ydel, int lane, int tile0)
+                                            const double *ydel, int lane, int tile0, int prow, double *pcb)
 {
+    // fold: the projection rows V^T sit in padding rows prow..prow+3 of the packed aerosol operator (api.hip), so the
+    // dense pass below already computes V^T X^sr in the accumulator quad of those rows; pcb = this lane's slot in the
+    // (unused) padding rows of the LDS buffer through which the owning wave hands the projections to the others
+    constexpr bool fold = FOLD;          // the caller selects it: RAY >= 0, aerosol present, prow >= 0
     struct BRaw { v2d xp[CT], xm[CT]; };
     auto load_b = [&](BRaw &b, int m) {
 #pragma unroll
@@ -143,7 +147,7 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
                 for (int rt = 0; rt < NA; rt++) f.a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
-            if (RAY >= 0) f.v = vp[(size_t)m * 64];
+            if (RAY >= 0 && !fold) f.v = vp[(size_t)m * 64];
         };
         auto mma = [&](const AFrag &f, const BRaw &b) {
             v2d ba[CT], bb[CT];
@@ -163,7 +167,7 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
                     acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
                     acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
                 }
-            if (RAY >= 0) {
+            if (RAY >= 0 && !fold) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
                     const v2d bq = RAY ? bb[ct] : ba[ct];
@@ -200,6 +204,20 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
             }
             if (m < ks2h) { load_b(b0, m); mma(f0, b0); }
         }
+        if (fold) {
+            // accumulator register 3 of the tile holding prow is row prow + (lane>>4): the projection, in the B-operand
+            // layout of the K = 4 expansion step.  The owner publishes it and clears it (those rows are padding).
+            const int ptile = prow >> 4;
+#pragma unroll
+            for (int rt = 0; rt < NA; rt++)
+                if (tile0 + rt * NW == ptile) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++) {
+                        pcb[ct * 16 * FS] = acc[RAY > 0][rt][ct][3];
+                        acc[RAY > 0][rt][ct][3] = 0.;
+                    }
+                }
+        }
         // XDEL of the output level: every accumulator register of a lane belongs to one column
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
@@ -234,11 +252,12 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
         if (m < ks2h) prj(v0, b0);
     }
     if (RAY >= 0) {
+        if (fold) __syncthreads();             // every wave of the workgroup passes exactly one barrier here (see the call site)
         // register 0 of pr holds row (lane>>4) in 0..3, column lane&15: exactly the B-operand layout of one
         // K = 4 step, so the expansion U * (YDEL o pr) needs no data movement
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
-            const double q = pr[ct][0] * ydel[ct * 16 + (lane & 15)];
+            const double q = (fold ? pcb[ct * 16 * FS] : pr[ct][0]) * ydel[ct * 16 + (lane & 15)];
 #pragma unroll
             for (int rt = 0; rt < NA; rt++) {
                 const double u = uf[(size_t)(tile0 + rt * NW) * 64 + lane];
@@ -391,6 +410,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
     const bool tile_a = wv * 16 < KH;
     const bool tile_b = RTWH > 1 && (wv + NW) * 16 < KH;
     const double *bx = cbuf + (lane & 15) * FS + 2 * (lane >> 4);
+    double *pcb = cbuf + (lane & 15) * FS + (cx.prow >= 0 ? cx.prow : 0) + (lane >> 4);    // see gemm_source (fold)
 
     {   // one workgroup = one bin (grid = nb): no bin loop, so per-bin constants are not kept live elsewhere
         const int b = blockIdx.x;
@@ -636,20 +656,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     const double *vtp = cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128;
                     const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
                     // RAY: half system the molecular operator acts on (A for even s, B for odd s), none for s > 2
+                    const bool fold = s <= 2 && has_aer && cx.prow >= 0;       // projection rows ride in the dense pass
                     auto contract = [&](auto na_tag) {
                         constexpr int NA = decltype(na_tag)::value;
-                        if (s > 2)
-                            gemm_source<NA, -1, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
-                                                                       xdel + l0, ydel + l0, lane, wv);
-                        else if (s & 1)
-                            gemm_source<NA, 1, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
-                                                                      xdel + l0, ydel + l0, lane, wv);
-                        else
-                            gemm_source<NA, 0, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,
-                                                                      xdel + l0, ydel + l0, lane, wv);
+#define SOS_GEMM(RAYV, FOLDV)                                                                                          \
+    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,       \
+                                                        xdel + l0, ydel + l0, lane, wv, cx.prow, pcb)
+                        if (s > 2) SOS_GEMM(-1, false);
+                        else if (s & 1) { if (fold) SOS_GEMM(1, true); else SOS_GEMM(1, false); }
+                        else { if (fold) SOS_GEMM(0, true); else SOS_GEMM(0, false); }
+#undef SOS_GEMM
                     };
                     if (tile_b) contract(std::integral_constant<int, RTWH>());
                     else if (tile_a) contract(std::integral_constant<int, 1>());
+                    else if (fold) __syncthreads();                            // the barrier of the folded projection
                     __syncthreads();             // non-BIG: every wave has read the field; BIG: previous chunk copied out
                     PH(2);
                     // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
