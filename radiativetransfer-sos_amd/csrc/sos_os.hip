@@ -113,8 +113,9 @@ __device__ __forceinline__ double queue_term(double d, double g)
 // base (column lane&15, k-quad lane>>4) in the field (LDS, or the HBM scratch of the BIG variants) with level stride FS.
 // Software pipeline: the A fragments (global/L2) and the raw B operands X+, X- (LDS) of k-pair m+1 are requested
 // before the 16+ MFMAs of k-pair m are issued (two register sets each, used alternately, no copies), so neither the
-// L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection rides in the same loop (RAY = half
-// system it acts on, -1 = none): 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
+// L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection of the molecular operator (RAY = half
+// system it acts on, -1 = none) either comes for free (FOLD: its four rows are packed into padding rows of the dense
+// operator) or rides in the same loop as 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
 template <int NA, int RAY, bool FOLD, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B>
 __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
                                             const double *__restrict__ vt, const double *__restrict__ uf,
