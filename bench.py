@@ -8,13 +8,23 @@ a batch of `--bins` bins per GPU already resident in HBM: fused SOS_OS solve of 
 aggregation (+ one RCCL all-reduce of the band result when N > 1).  Bins are sharded over ranks with no
 data-path collective besides that reduce; per-GPU work is fixed as N grows ("weak").
 
-python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run, one rank/GPU)
-Rank 0 prints ONE JSON line.
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no launcher environment (WORLD_SIZE unset) the script starts its own N ranks through
+`python -m torch.distributed.run` as a CHILD process, before anything touches the GPU, and exits with the child's
+code; under a launcher (the driver's torch.distributed.run) it is one rank.  Rank 0 prints ONE JSON line.
+
+--workload realistic (also appended to the default N = 1 line as "realistic_mix"): the same wavelength with the level
+grids SOS_PROFILE really produces (NT 117...426 from seeded gas columns, made on the device by sosgpu_profile), i.e. the
+streamed-field variant of the solver.
+--dry-run: CPU rehearsal of the multi-rank path (gloo, fabricated partials, no solver) used by tests/test_dist_cpu.py.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X dense FP64 MFMA peak (MI355X_MICROARCH.md); scripts/ubench_mfma_peak.hip measures 78.1 on the box
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md
 
 
 def build_workload(S, nb, nt, seed, g):
@@ -34,6 +45,17 @@ def build_workload(S, nb, nt, seed, g):
     h, x, y, iborm = S.rescale_profile(bins["h"], bins["xdel"], bins["ydel"], 0.0, 0.95, 0.95, os_nb)
     return dict(mu=mu, w=w, n0=n0, os_nb=os_nb, coefs=(al, be, ga, ze), h=h, xdel=x, ydel=y, zprof=bins["zprof"],
                 aik=bins["aik"], iborm=iborm)
+
+
+def realistic_columns(nb, seed=5):
+    """Seeded gas columns of the realistic mix (k_b log-uniform in [1e-3, 30]) on 50 descending altitudes:
+    cumulative absorption optical depth per bin, as SOS_ABSPROFILE hands it to SOS_PROFILE."""
+    alt = np.concatenate([np.linspace(120.0, 30.0, 10), np.linspace(28.0, 0.0, 40)])
+    col = np.exp(-alt / 7.0)
+    col[0] = 0.0
+    rng = np.random.default_rng(seed)
+    scale = np.exp(rng.uniform(np.log(1e-3), np.log(30.0), nb))
+    return alt, scale[:, None] * col[None, :]
 
 
 def cpu_baseline(wl, nsample):
@@ -66,6 +88,152 @@ def cpu_baseline(wl, nsample):
                     done, "amdflang -O2 build of the reference Fortran" if kind == "reference" else "C restatement -O2", dt))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torchrun and relay its exit
+    code.  Nothing in this process has touched the GPU yet (no torch import)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """CPU rehearsal of the N-rank path: process group (gloo), shard ranges, packed partials, the one SUM all-reduce +
+    the MAX pair, finish.  No solver: partials are fabricated from a seeded generator, so rank 0 can check the reduce."""
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("radiativetransfer-sos_amd")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, s1 = 5, 4
+    w = 2 * n + 1
+    nb_tot = args.bins * world
+    rng = np.random.default_rng(7)
+    rec_all = rng.normal(size=(nb_tot, s1, 3, w))
+    aik = rng.dirichlet(np.ones(nb_tot))
+    nord = rng.integers(1, s1 + 1, nb_tot)
+    lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
+    prec = torch.from_numpy((aik[lo:hi, None, None, None] * rec_all[lo:hi]).sum(0, keepdims=True))
+    sc = np.zeros((1, 10 + n))
+    sc[0, 6], sc[0, 7], sc[0, 8] = aik[lo:hi].sum(), (nord[lo:hi].max() if hi > lo else 0), (-nord[lo:hi].min() if hi > lo else -2147483647.)
+    sc[0, 3:6] = aik[lo:hi].sum()
+    buf = pkg.dist.all_reduce_partial(pkg.dist.pack_partial(prec, torch.from_numpy(sc)), 10 + n)
+    rec, scal = pkg.dist.unpack_partial(buf, prec.shape)
+    fin = pkg.dist.finish_scalars(scal)
+    ok = bool(np.allclose(rec[0].numpy(), (aik[:, None, None, None] * rec_all).sum(0), rtol=1e-12, atol=1e-14)
+              and abs(fin["sum_aik"][0] - 1.0) < 1e-12 and fin["n_orders"][0] == nord.max() and fin["min_orders"][0] == nord.min())
+    if rank == 0:
+        print(json.dumps(dict(metric="CKD spectral bins/sec (full Stokes I,Q,U, TOA+surface)", value=None, unit="bins/s",
+                              n_gpus=world, steps=0, warmup=0, dry_run=True, reduce_ok=ok,
+                              config=dict(workload="dry run (gloo, fabricated partials)", bins_per_gpu=args.bins))))
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def timed_steps(step, fence, steps, warmup, world, dist, device, torch):
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_ms(cx, bins, out, reps=3):
+    durs = []
+    for _ in range(reps):
+        cx.solve(bins, out)
+        durs.append(cx.last_solve_ms())
+    return float(np.mean(durs))
+
+
+def pmc_traffic(tag, **match):
+    """HBM traffic of one launch: rocprofv3 PMC passes of this same command, summarised (with the gfx950 corrections of
+    MI355X_MICROARCH.md) by scripts/summarize_profiles.py into profiles/; None when the workload differs."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_pmc_hbm%s.json" % (rnd, tag))) as f:
+                pm = json.load(f)
+            if all(pm.get(k) == v for k, v in match.items()):
+                return pm["k_sos_os_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g):
+    """The level grids real CKD bins get (NT >= CTE_OS_NT_MIN = 100, SOS.h:229): profiles made on the device by
+    sosgpu_profile from seeded gas columns, solved by the streamed-field variant.  Returns the result dict."""
+    S = pkg.synth
+    mu, w, n0 = S.gauss_angles(40, 35.0)
+    os_nb = 80
+    al, be, ga, ze = S.hg_phase(os_nb, g)
+    cx = pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=os_nb, ro=0.1)
+    nb_tot = nbins * world
+    lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
+    alt, tabs = realistic_columns(nb_tot)
+    aik_all = np.random.default_rng(1234).dirichlet(np.ones(nb_tot))
+    order = np.argsort(-tabs[lo:hi, -1], kind="stable")           # cost-sorted (thickest gas column first)
+    bins = cx.make_profiles(hi - lo, 0.0948, 8.0, 0.3, 2.0, alt, tabs[lo:hi][order], piz=0.95, piztr=0.95)
+    aik = torch.from_numpy(aik_all[lo:hi][order]).to(cx.device)
+    out = cx.alloc_outputs(hi - lo)
+    torch.cuda.synchronize()
+
+    def step():
+        cx.solve(bins, out)
+        rec, scal = cx.aggregate(out, aik, scal=bins["scal"])
+        return pkg.dist.all_reduce_partial(pkg.dist.pack_partial(rec, scal), scal.shape[1])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dt = timed_steps(step, fence, steps, warmup, world, dist, cx.device, torch)
+    kms = kernel_ms(cx, bins, out, 2)
+    flops_ref, flops_exe = cx.solve_flops(bins, out)
+    nt = bins["nt"].cpu().numpy().astype(np.int64)
+    igl = out["iglast"].cpu().numpy().astype(np.int64)
+    nsteps = np.clip(igl - 1, 0, None).sum(axis=1)                # contraction steps (scattering orders >= 2) per bin
+    passes = np.clip(igl, 0, None).sum(axis=1)                    # field passes per bin: every scattering order, order 1 included
+    # algorithmic field traffic of the streamed variant: each pass writes the 6N-row field of NT+1 levels once and every
+    # pass but the first of a Fourier order reads it once (DESIGN.md section 4)
+    field = (nt + 1) * 6 * cx.n * 8.0
+    nord = out["norders"].cpu().numpy().astype(np.int64)
+    bytes_alg = float((field * (2 * passes - np.clip(nord, 0, None))).sum())
+    ach = bytes_alg / (kms * 1e-3) / 1e9
+    tf = flops_exe / (kms * 1e-3) / 1e12
+    res = dict(value=nb_tot * steps / dt, unit="bins/s", ms_per_step=1e3 * dt / steps, steps=steps, warmup=warmup,
+               config=dict(workload="same wavelength as the headline, level grids of SOS_PROFILE for seeded gas columns "
+                                    "(k log-uniform 1e-3..30): NT %d...%d, mean %.0f; %d bins/GPU/step" % (
+                                        nt.min(), nt.max(), nt.mean(), nbins),
+                           bins_per_gpu=nbins, nt_min=int(nt.min()), nt_mean=float(nt.mean()), nt_max=int(nt.max()),
+                           mean_fourier_orders=float(nord.mean()), mean_scattering_steps=float(nsteps.mean())),
+               roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                             traffic=pmc_traffic("_realistic", bins_per_gpu=nbins),
+                             kernel="k_sos_stream<4,2,false,false>", kernel_ms=kms, bytes_per_launch=bytes_alg,
+                             bytes_counted="field written once per scattering order and read once per order >= 2: "
+                                           "(NT+1) x 6N x 8 B each",
+                             mfma_tflops=tf, mfma_frac=tf / FP64_PEAK_TFLOPS))
+    cx.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,27 +242,47 @@ def main():
     ap.add_argument("--bins", type=int, default=4096, help="CKD bins per GPU per step")
     ap.add_argument("--nt", type=int, default=30)
     ap.add_argument("--g", type=float, default=0.75)
+    ap.add_argument("--workload", choices=["headline", "realistic"], default="headline")
     ap.add_argument("--cpu-sample", type=int, default=224, help="bins timed on the CPU baseline (about 15 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-mix", action="store_true", help="skip the appended realistic_mix measurement (N = 1 default run)")
     ap.add_argument("--no-sort", action="store_true", help="keep the bins in generation order (default: cost-sorted upload)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank path (gloo, no solver)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if args.dry_run:
+        sys.exit(dry_run(args, world, rank))
 
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module("radiativetransfer-sos_amd")
     S = pkg.synth
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = args.gpus > 1 or world > 1
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
+    base = dict(metric="CKD spectral bins/sec (full Stokes I,Q,U, TOA+surface)", unit="bins/s", n_gpus=world,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic")
+
+    if args.workload == "realistic":
+        r = run_realistic(pkg, torch, dist, world, rank, args.bins, args.steps, args.warmup, args.g)
+        r["config"]["parallelism"] = "bins sharded x%d" % world
+        if rank == 0:
+            print(json.dumps(dict(base, **r)))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # every rank owns `bins` bins of one global band of world*bins bins (weights normalised globally)
     nb_tot = args.bins * world
@@ -114,52 +302,23 @@ def main():
         cx.solve(bins, out)
         rec, scal = cx.aggregate(out, aik)
         buf = pkg.dist.pack_partial(rec, scal)
-        return pkg.dist.all_reduce_partial(buf)
+        return pkg.dist.all_reduce_partial(buf, scal.shape[1])
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kms.append(None)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_steps(step, fence, args.steps, args.warmup, world, dist, cx.device, torch)
 
-    # roofline of the dominant kernel (k_sos_os): HIP-event duration of the LAST timed launch on its own
-    # stream + a few extra launches for an average, algorithmic flops counted from the run's own
-    # Fourier/scattering-order counts (SURVEY 8d W_step).
-    durs = []
-    for _ in range(3):
-        cx.solve(bins, out)
-        durs.append(cx.last_solve_ms())
-    kern_ms = float(np.mean(durs))
+    # roofline of the dominant kernel (k_sos_os): HIP-event duration on its own stream (sosgpu_last_solve_ms), averaged
+    # over a few launches; algorithmic flops counted from the run's own Fourier/scattering-order counts.
+    kern_ms = kernel_ms(cx, bins, out)
     flops_ref, flops_exe = cx.solve_flops(bins, out)
     achieved = flops_exe / (kern_ms * 1e-3) / 1e12
-    # HBM traffic of one launch: rocprofv3 PMC passes of this same command, summarised (with the gfx950 corrections
-    # of MI355X_MICROARCH.md) by scripts/summarize_profiles.py into profiles/; null when the workload differs
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
-            pm = json.load(f)
-        if pm.get("bins_per_gpu") == args.bins and pm.get("nt") == args.nt:
-            traffic = pm["k_sos_os_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic = pmc_traffic("", bins_per_gpu=args.bins, nt=args.nt)
 
-    res = dict(metric="CKD spectral bins/sec (full Stokes I,Q,U, TOA+surface)", value=nb_tot * args.steps / dt,
-               unit="bins/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+    res = dict(base, value=nb_tot * args.steps / dt, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                config=dict(workload="single-wavelength aerosol+Rayleigh, 40 Gauss angles (N=41), NT=%d layers, OS_NB=80, "
                                     "Lambertian rho=0.1, HG g=%.2f, %d CKD bins/GPU/step" % (args.nt, args.g, args.bins),
                            bins_per_gpu=args.bins, nt=args.nt, n_dirs=41, os_nb=80, parallelism="bins sharded x%d" % world,
@@ -170,13 +329,16 @@ def main():
                              flops_counted="parity form (two 3N x 3Nw half systems, Nw = weighted directions) + rank-4 molecular form + formal solution, unpadded",
                              reference_algorithm_flops_per_launch=flops_ref,
                              reference_algorithm_tflops=flops_ref / (kern_ms * 1e-3) / 1e12))
+    nord = out["norders"].cpu().numpy()
+    cx.close()
+    if world == 1 and not args.no_mix:
+        res["realistic_mix"] = run_realistic(pkg, torch, dist, world, rank, args.bins, max(2, args.steps // 5), 1, args.g)
     if rank == 0:
-        nord = out["norders"].cpu().numpy()
         res["config"]["mean_fourier_orders"] = float(nord.mean())
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample)
         print(json.dumps(res))
-    if use_dist:
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -36,6 +36,7 @@ extern "C" {
 #define SOSGPU_E_HIP        -2   /* HIP runtime error (sosgpu_last_hip_error) */
 #define SOSGPU_E_UNSUPPORTED -3  /* size outside the compiled kernel variants */
 #define SOSGPU_E_NODEVICE   -4   /* no gfx950 device visible */
+#define SOSGPU_E_RCCL       -5   /* librccl missing or an RCCL call failed */
 
 /* Per-wavelength description (everything SOS_OS receives that does not depend on the CKD bin). */
 typedef struct sosgpu_wave {
@@ -93,8 +94,10 @@ int  sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out);
  *              0 = standard output (ZOUT = -1: TOA up, ground down).  May be NULL (= all 0).
  *  d_zz[nb]    interpolation weight ZZ (SOS_OS.F:1520); ignored when jout = 0.  May be NULL.
  * outputs
- *  d_rec[nb][iborm_max+1][3][W]  Fourier records (orders not run are zero)
- *  d_norders[nb]                 number of Fourier orders run (int32)
+ *  d_rec[nb][iborm_max+1][3][W]  Fourier records; only orders 0..d_norders[b]-1 are written (the reference's FICOS file
+ *                                of a bin holds one record per order run, SOS_OS.F:1571-1575)
+ *  d_norders[nb]                 number of Fourier orders run (int32); -1 = malformed bin (NT < 1, NT >= lp, IBORM out of
+ *                                range: the reference's IER = -1), nothing else is written for it
  *  d_iglast[nb][iborm_max+1]     last scattering order computed per Fourier order (int32)
  *  d_flux[nb][2]                 EMOINS, EPLUS (SOS_OS.F:1447-1456)
  */
@@ -105,16 +108,38 @@ int  sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const 
 /* Replaces SOS_AGGREGATE (SOS_AGGREGATE.F:372-488) for nseg independent wavelengths/bands at once:
  * segment g covers bins seg[g]..seg[g+1]-1 of d_rec; seg[0] = 0, seg[nseg] = nb.  One big band (nseg = 1,
  * nb > 128) is reduced in chunks of 64 bins (deterministic; the strict serial bin order of the reference is kept for
- * small bands and multi-band calls).
- *  d_scal[nb][4]  per-bin scalars: TDIFMUS, TTOT_TRONC, TTOT_VRAI, TAUOUT
- *  d_out_rec[nseg][iborm_max+1][3][W] = sum_b aik[b] * rec[b]
- *  d_out_scal[nseg][8] = sum aik*{TDIFMUS, EMOINS, EPLUS}, sum aik*exp(-{TTOT_TRONC,TTOT_VRAI,TAUOUT}),
- *                         sum aik, max norders     (the -ln of the three transmissions is applied by
- *                         sosgpu_aggregate_finish after the cross-GPU reduce)
+ * small bands and multi-band calls).  nb = 0 (a rank whose shard of the band is empty) is allowed with nseg = 1: the
+ * outputs are the neutral element of the cross-rank reduce.
+ *  d_scal[nb][4]     per-bin scalars: TDIFMUS, TTOT_TRONC, TTOT_VRAI, TAUOUT
+ *  d_tdifmug[nb][N]  per-bin diffuse transmissions TDIFMUG(1..N) of the -SOS.Trans option (SOS.F:611-635), or NULL
+ *  d_out_rec[nseg][iborm_max+1][3][W] = sum_b aik[b] * rec[b]   (orders a bin did not run count as zero records,
+ *                    SOS_AGGREGATE.F:357-413; bins with norders < 0 are skipped)
+ *  d_out_scal[nseg][SOSGPU_SCAL_BASE + N]:
+ *      [0..2] sum aik*{TDIFMUS, EMOINS, EPLUS}     [3..5] sum aik*exp(-{TTOT_TRONC, TTOT_VRAI, TAUOUT})
+ *      [6]    sum aik        [7] max norders       [8] -(min norders): > 0 when a bin of the segment failed
+ *      [9]    0              [10..10+N) sum aik*TDIFMUG(j)     (SOS_AGGREGATE.F:452-459)
+ *   Across GPUs elements 7 and 8 combine with MAX, all others (and d_out_rec) with SUM; the -ln of the three
+ *   transmissions (SOS_AGGREGATE.F:467-488) is applied afterwards (sosgpu_reduce does all of this).
  */
+#define SOSGPU_SCAL_BASE 10
 int  sosgpu_aggregate(sosgpu_ctx *cx, int nb, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
-                      double *d_out_rec, double *d_out_scal, void *stream);
+                      const double *d_tdifmug, double *d_out_rec, double *d_out_scal, void *stream);
+
+/* Cross-GPU step of SOS_AGGREGATE for callers without torch.distributed (C / Fortran hosts): one RCCL
+ * all-reduce (ncclDouble, ncclSum) over xGMI of the packed buffer d_buf[nseg][(iborm_max+1)*3*W + SOSGPU_SCAL_BASE + N]
+ * (records followed by the scalar block, the layout sosgpu_pack writes) plus one 2-element MAX all-reduce per segment
+ * for elements 7 and 8.  `comm` is an ncclComm_t (as void*) the caller created -- sosgpu_comm_* wrap ncclGetUniqueId /
+ * ncclCommInitRank / ncclCommDestroy so that a host needs no RCCL headers.  librccl is resolved at the first call
+ * (dlopen), so single-GPU users carry no RCCL dependency.  nranks = 1 is a no-op. */
+#define SOSGPU_UNIQUE_ID_BYTES 128
+int  sosgpu_comm_unique_id(char id[SOSGPU_UNIQUE_ID_BYTES]);
+int  sosgpu_comm_init_rank(void **comm, int nranks, const char id[SOSGPU_UNIQUE_ID_BYTES], int rank);
+int  sosgpu_comm_destroy(void *comm);
+/* d_out_rec / d_out_scal of sosgpu_aggregate -> d_buf (device-to-device copies on `stream`) and back. */
+int  sosgpu_pack(sosgpu_ctx *cx, int nseg, const double *d_out_rec, const double *d_out_scal, double *d_buf, void *stream);
+int  sosgpu_unpack(sosgpu_ctx *cx, int nseg, const double *d_buf, double *d_out_rec, double *d_out_scal, void *stream);
+int  sosgpu_reduce(sosgpu_ctx *cx, void *comm, int nseg, double *d_buf, void *stream);
 
 /* Replaces SOS_GLITTER (SOS_GLITTER.F:229-371: SOS_GSF + SOS_MAT_FRESNEL + SOS_MAT_REFLEXION +
  * SOS_MISE_FORMAT, no temporary files).  Host inputs mu[n], chr[n] (Gauss weights), wind (m/s), ind (water

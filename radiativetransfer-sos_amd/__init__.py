@@ -12,8 +12,8 @@ __all__ = ["synth", "capi", "solver", "build_ext", "SosContext"]
 
 def __getattr__(name):
     import importlib
-    if name in ("capi", "solver", "build_ext", "run_sos", "dist", "surface", "trphi"):
+    if name in ("capi", "solver", "build_ext", "run_sos", "dist", "surface", "ckd", "launch"):
         return importlib.import_module("." + name, __name__)
-    if name == "SosContext":
-        return importlib.import_module(".solver", __name__).SosContext
+    if name in ("SosContext", "SosBinError"):
+        return getattr(importlib.import_module(".solver", __name__), name)
     raise AttributeError(name)

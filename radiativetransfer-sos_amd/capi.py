@@ -16,8 +16,10 @@ EXPORTS = [
     "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
-    "sosgpu_debug_phase_buffer",
+    "sosgpu_debug_phase_buffer", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
+    "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce",
 ]
+SCAL_BASE = 10          # SOSGPU_SCAL_BASE: scalar block of sosgpu_aggregate = SCAL_BASE + N doubles
 
 
 class SosgpuError(RuntimeError):
@@ -65,7 +67,19 @@ def lib():
         L.sosgpu_os_solve.restype = i32
         L.sosgpu_os_solve.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sosgpu_aggregate.restype = i32
-        L.sosgpu_aggregate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_aggregate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_comm_unique_id.restype = i32
+        L.sosgpu_comm_unique_id.argtypes = [vp]
+        L.sosgpu_comm_init_rank.restype = i32
+        L.sosgpu_comm_init_rank.argtypes = [C.POINTER(vp), i32, vp, i32]
+        L.sosgpu_comm_destroy.restype = i32
+        L.sosgpu_comm_destroy.argtypes = [vp]
+        L.sosgpu_pack.restype = i32
+        L.sosgpu_pack.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.sosgpu_unpack.restype = i32
+        L.sosgpu_unpack.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.sosgpu_reduce.restype = i32
+        L.sosgpu_reduce.argtypes = [vp, vp, i32, vp, vp]
         L.sosgpu_ctx_bytes.restype = C.c_size_t
         L.sosgpu_ctx_bytes.argtypes = [vp]
         L.sosgpu_profile.restype = i32

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <dlfcn.h>
 #include <vector>
 
 static thread_local int g_last_hip = 0;
@@ -49,6 +50,7 @@ extern "C" const char *sosgpu_strerror(int code)
     case SOSGPU_E_HIP: return "HIP runtime error";
     case SOSGPU_E_UNSUPPORTED: return "problem size outside the compiled kernel variants";
     case SOSGPU_E_NODEVICE: return "no gfx950 device visible";
+    case SOSGPU_E_RCCL: return "RCCL unavailable or an RCCL call failed";
     default: return "unknown error";
     }
 }
@@ -187,8 +189,12 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
         sosgpu_destroy(cx);
         return rc;
     }
-    HIPCHK(hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double)));
-    HIPCHK(hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double)));
+    if (hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double)) != hipSuccess ||
+        hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double)) != hipSuccess) {
+        g_last_hip = (int)hipGetLastError();
+        sosgpu_destroy(cx);
+        return SOSGPU_E_HIP;
+    }
     if (hipEventCreate(&cx->ev0) != hipSuccess || hipEventCreate(&cx->ev1) != hipSuccess) {
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;
@@ -291,7 +297,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
         const size_t need = per_bin * per_launch;
         if (need > cx->scratch_doubles) {
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipDeviceSynchronize());     // a solve of this context may still be in flight on another stream
             if (cx->scratch) (void)hipFree(cx->scratch);
             cx->scratch = nullptr;
             cx->scratch_doubles = 0;
@@ -310,8 +316,8 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
-        rc = launch_sos_os(cx->d, bn, nt_max, st);
-        if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
+        rc = launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
+        if (rc == -2) return SOSGPU_E_HIP;
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(cx->ev1, st));
@@ -357,28 +363,159 @@ extern "C" int sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, cons
     return SOSGPU_OK;
 }
 
+__global__ void k_aggregate_empty(int nel, int sw, double *out_rec, double *out_scal)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nel) out_rec[e] = 0.;
+    if (e < sw) out_scal[e] = (e == 8) ? -2147483647. : 0.;
+}
+
 extern "C" int sosgpu_aggregate(sosgpu_ctx *cx, int nb, int nseg, const int32_t *d_seg, const double *d_aik,
                                 const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
-                                double *d_out_rec, double *d_out_scal, void *stream)
+                                const double *d_tdifmug, double *d_out_rec, double *d_out_scal, void *stream)
 {
-    if (!cx || nb < 1 || nseg < 1 || nseg > nb || !d_seg || !d_aik || !d_rec || !d_norders || !d_flux || !d_scal ||
-        !d_out_rec || !d_out_scal)
-        return SOSGPU_E_ARG;
+    if (!cx || nb < 0 || nseg < 1 || !d_out_rec || !d_out_scal) return SOSGPU_E_ARG;
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;
+    const int nel = (cx->d.smax + 1) * 3 * cx->d.w;
+    if (nb == 0) {          // empty shard of a band: neutral element of the cross-rank reduce
+        if (nseg != 1) return SOSGPU_E_ARG;
+        const int sw = SOSGPU_SCAL_BASE + cx->d.n;
+        k_aggregate_empty<<<(std::max(nel, sw) + 255) / 256, 256, 0, st>>>(nel, sw, d_out_rec, d_out_scal);
+        HIPCHK(hipGetLastError());
+        return SOSGPU_OK;
+    }
+    if (nseg > nb || !d_seg || !d_aik || !d_rec || !d_norders || !d_flux || !d_scal) return SOSGPU_E_ARG;
     const int max_chunks = 4096;
     const int nb_single = (nseg == 1) ? nb : 0;      // one band: big batches use the chunked reduction
     if (nb_single > 128 && !cx->agg_partial) {
-        const size_t nel = (size_t)(cx->d.smax + 1) * 3 * cx->d.w;
         void *q = nullptr;
-        HIPCHK(hipMalloc(&q, nel * max_chunks * sizeof(double)));
+        HIPCHK(hipMalloc(&q, (size_t)nel * max_chunks * sizeof(double)));
         cx->agg_partial = (double *)q;
         cx->allocs.push_back(q);
-        cx->bytes += nel * max_chunks * sizeof(double);
+        cx->bytes += (size_t)nel * max_chunks * sizeof(double);
     }
-    launch_aggregate(cx->d, nseg, d_seg, d_aik, d_rec, d_norders, d_flux, d_scal, d_out_rec, d_out_scal, st,
+    launch_aggregate(cx->d, nseg, d_seg, d_aik, d_rec, d_norders, d_flux, d_scal, d_tdifmug, d_out_rec, d_out_scal, st,
                      nb_single, cx->agg_partial, max_chunks);
     HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-GPU reduce of the band partials over RCCL (xGMI).  librccl is resolved lazily with dlopen: a process that
+// already holds an RCCL (torch's) gets that one, single-GPU users never load it.
+// ---------------------------------------------------------------------------------------------
+struct Uid { char internal[SOSGPU_UNIQUE_ID_BYTES]; };   // ncclUniqueId (nccl.h: 128 opaque bytes, passed by value)
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Uid, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+};
+}  // namespace
+static Rccl g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.h) return 0;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return SOSGPU_E_RCCL;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GroupStart ||
+        !g_rccl.GroupEnd)
+        return SOSGPU_E_RCCL;
+    g_rccl.h = h;
+    return 0;
+}
+
+extern "C" int sosgpu_comm_unique_id(char id[SOSGPU_UNIQUE_ID_BYTES])
+{
+    if (!id) return SOSGPU_E_ARG;
+    if (int rc = rccl_load()) return rc;
+    Uid u;
+    memset(&u, 0, sizeof u);
+    if (g_rccl.GetUniqueId(&u) != 0) return SOSGPU_E_RCCL;
+    memcpy(id, u.internal, SOSGPU_UNIQUE_ID_BYTES);
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_comm_init_rank(void **comm, int nranks, const char id[SOSGPU_UNIQUE_ID_BYTES], int rank)
+{
+    if (!comm || !id || nranks < 1 || rank < 0 || rank >= nranks) return SOSGPU_E_ARG;
+    if (int rc = rccl_load()) return rc;
+    Uid u;
+    memcpy(u.internal, id, SOSGPU_UNIQUE_ID_BYTES);
+    return g_rccl.CommInitRank(comm, nranks, u, rank) == 0 ? SOSGPU_OK : SOSGPU_E_RCCL;
+}
+
+extern "C" int sosgpu_comm_destroy(void *comm)
+{
+    if (!comm) return SOSGPU_OK;
+    if (int rc = rccl_load()) return rc;
+    return g_rccl.CommDestroy(comm) == 0 ? SOSGPU_OK : SOSGPU_E_RCCL;
+}
+
+extern "C" int sosgpu_pack(sosgpu_ctx *cx, int nseg, const double *d_out_rec, const double *d_out_scal, double *d_buf, void *stream)
+{
+    if (!cx || nseg < 1 || !d_out_rec || !d_out_scal || !d_buf) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(cx->device));
+    const size_t nel = (size_t)(cx->d.smax + 1) * 3 * cx->d.w, sw = SOSGPU_SCAL_BASE + cx->d.n, row = nel + sw;
+    HIPCHK(hipMemcpy2DAsync(d_buf, row * 8, d_out_rec, nel * 8, nel * 8, nseg, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIPCHK(hipMemcpy2DAsync(d_buf + nel, row * 8, d_out_scal, sw * 8, sw * 8, nseg, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_unpack(sosgpu_ctx *cx, int nseg, const double *d_buf, double *d_out_rec, double *d_out_scal, void *stream)
+{
+    if (!cx || nseg < 1 || !d_out_rec || !d_out_scal || !d_buf) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(cx->device));
+    const size_t nel = (size_t)(cx->d.smax + 1) * 3 * cx->d.w, sw = SOSGPU_SCAL_BASE + cx->d.n, row = nel + sw;
+    HIPCHK(hipMemcpy2DAsync(d_out_rec, nel * 8, d_buf, row * 8, nel * 8, nseg, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIPCHK(hipMemcpy2DAsync(d_out_scal, sw * 8, d_buf + nel, row * 8, sw * 8, nseg, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SOSGPU_OK;
+}
+
+// the two MAX-combined scalars of every segment are saved before the SUM all-reduce and restored from their own MAX
+// all-reduce afterwards
+__global__ void k_reduce_save(int nseg, size_t row, size_t off, double *buf, double *mx, int restore)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * nseg) return;
+    double *p = buf + (size_t)(i / 2) * row + off + 7 + (i & 1);
+    if (restore) *p = mx[i]; else mx[i] = *p;
+}
+
+extern "C" int sosgpu_reduce(sosgpu_ctx *cx, void *comm, int nseg, double *d_buf, void *stream)
+{
+    if (!cx || nseg < 1 || !d_buf) return SOSGPU_E_ARG;
+    if (!comm) return SOSGPU_OK;                  // single rank
+    if (int rc = rccl_load()) return rc;
+    HIPCHK(hipSetDevice(cx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nel = (size_t)(cx->d.smax + 1) * 3 * cx->d.w, row = nel + SOSGPU_SCAL_BASE + cx->d.n;
+    double *mx = nullptr;
+    HIPCHK(hipMalloc((void **)&mx, (size_t)2 * nseg * sizeof(double)));
+    k_reduce_save<<<(2 * nseg + 63) / 64, 64, 0, st>>>(nseg, row, nel, d_buf, mx, 0);
+    const int ncclDouble = 8, ncclSum = 0, ncclMax = 2;    // nccl.h enumerators (ncclFloat64 = 8)
+    int bad = g_rccl.AllReduce(d_buf, d_buf, row * nseg, ncclDouble, ncclSum, comm, st);
+    bad |= g_rccl.AllReduce(mx, mx, (size_t)2 * nseg, ncclDouble, ncclMax, comm, st);
+    k_reduce_save<<<(2 * nseg + 63) / 64, 64, 0, st>>>(nseg, row, nel, d_buf, mx, 1);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(mx);
+    if (bad) return SOSGPU_E_RCCL;
+    HIPCHK(e);
     return SOSGPU_OK;
 }
 
@@ -603,7 +740,7 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     a.z_ng = cx->prof_ng; a.h_ng = cx->prof_ng + NG; a.pca_ng = cx->prof_ng + 2 * NG; a.pcm_ng = cx->prof_ng + 3 * NG;
     a.prof = d_prof; a.zprof = d_zprof; a.zz = d_zz; a.scal = d_scal; a.nt = d_nt; a.iborm = d_iborm; a.jout = d_jout;
     launch_profile(a, st);
-    if (hipGetLastError() != hipSuccess) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
+    HIPCHK(hipGetLastError());
     return SOSGPU_OK;
 }
 

@@ -5,8 +5,9 @@
 void launch_noyaux(const SosDev &cx, hipStream_t st);
 void launch_noyaux_fetch(const SosDev &cx, int s, double *d_out, hipStream_t st);
 
-// Fused successive-orders solver.  Returns 0, or SOSGPU_E_UNSUPPORTED when (N, max NT) has no variant.
-int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st);
+// Fused successive-orders solver.  Returns 0, SOSGPU_E_UNSUPPORTED when (N, max NT) has no variant, or -2 with the HIP
+// error code in *hip_err.
+int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err);
 // waves / row-tiles-per-wave / column tiles / LDS bytes the solver would use (for planning and tests); <0 if unsupported.
 int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_bytes, int *big);
 // doubles of per-bin scratch the field-in-HBM variant needs for lpb levels
@@ -14,7 +15,8 @@ size_t sos_os_scratch_doubles(int n, int lpb);
 
 void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,
-                      double *d_out_rec, double *d_out_scal, hipStream_t st, int nb_single, double *d_partial, int max_chunks);
+                      const double *d_tdifmug, double *d_out_rec, double *d_out_scal, hipStream_t st, int nb_single,
+                      double *d_partial, int max_chunks);
 
 void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
                     int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st);

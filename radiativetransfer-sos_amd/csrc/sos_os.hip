@@ -22,7 +22,6 @@
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
 #include <cstdlib>
-#include <cstdlib>
 #include <type_traits>
 #include "sos_common.h"
 #include "kernels.h"
@@ -422,7 +421,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
         const int jlo = (ZO && jout) ? jout - 1 : 0, jhi = (ZO && jout) ? jout : 0;
         // shape guard (uniform): a malformed bin is flagged (norders = -1), never indexed out of bounds
         if (nt < 1 || nt >= LPB || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
-            if (t == 0) bn.norders[b] = -1;
+            if (t == 0) { bn.norders[b] = -1; bn.flux[2 * b] = 0.; bn.flux[2 * b + 1] = 0.; }
+            for (int i = t; i < cx.smax + 1; i += NTH) bn.iglast[(size_t)b * (cx.smax + 1) + i] = 0;
             return;
         }
         const double *pf = bn.prof + (size_t)b * 3 * bn.lp;
@@ -786,8 +786,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             PH(6);
             if (!pf2) break;                                                         // SOS_OS.F:1585
         }
-        // orders not run: zero records and counts
-        for (int i = t + nord * 3 * W; i < S1 * 3 * W; i += NTH) recb[i] = 0.;
+        // orders not run: their records are left unwritten (sosgpu_aggregate reads norders and skips them, like the
+        // shorter FICOS file of the reference, SOS_AGGREGATE.F:357-413); only the counts are cleared
         for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
         if (t == 0) bn.norders[b] = nord;
 #ifdef SOS_PROFILE_PHASES
@@ -847,23 +847,22 @@ size_t sos_os_scratch_doubles(int n, int lpb)
 }
 
 template <int NW, int RTWH, int CT, bool BIG, bool ZO, bool SURF>
-static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st)
+static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st, int *hip_err)
 {
     auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO, SURF>;
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif
-#ifdef SOS_PROFILE_PHASES
-    if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
-#endif
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return -2;
-    const int grid = bn.nb;
-    kern<<<grid, 64 * NW, lds, st>>>(cx, bn);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        kern<<<bn.nb, 64 * NW, lds, st>>>(cx, bn);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return -2; }
+    return 0;
 }
 
-int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st)
+int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err)
 {
     int nw, rtw, ct, big;
     size_t lds;
@@ -875,10 +874,10 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
 #define V(NWV, R, C, B)                                                                   \
     if (nw == NWV && rtw == R && ct == C && big == B) {                                   \
         if (cx.imat_surf)                                                                 \
-            return zo ? launch_variant<NWV, R, C, B, true, true>(cx, bn, lds, st)         \
-                      : launch_variant<NWV, R, C, B, false, true>(cx, bn, lds, st);       \
-        return zo ? launch_variant<NWV, R, C, B, true, false>(cx, bn, lds, st)            \
-                  : launch_variant<NWV, R, C, B, false, false>(cx, bn, lds, st);          \
+            return zo ? launch_variant<NWV, R, C, B, true, true>(cx, bn, lds, st, hip_err)         \
+                      : launch_variant<NWV, R, C, B, false, true>(cx, bn, lds, st, hip_err);       \
+        return zo ? launch_variant<NWV, R, C, B, true, false>(cx, bn, lds, st, hip_err)            \
+                  : launch_variant<NWV, R, C, B, false, false>(cx, bn, lds, st, hip_err);          \
     }
     V(4, 1, 2, 0) V(4, 2, 2, 0) V(8, 2, 2, 0)
     V(4, 1, 4, 0) V(8, 1, 4, 0)

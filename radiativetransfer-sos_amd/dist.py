@@ -4,7 +4,8 @@ over xGMI on ROCm, "gloo" on CPU for tests).
 The bin loop of SOS_PROC (src/SOS_PROC.F:3459-3594) is embarrassingly parallel: every rank solves a
 contiguous slice of the bin list and forms its AIK-weighted partial sums locally; the only exchange is
 ONE all-reduce(sum, fp64) per wavelength/band of the packed buffer
-    [ (smax+1)*3*W Fourier records | 8 scalars ]
+    [ (smax+1)*3*W Fourier records | 10 + N scalars (TDIFMUS, EMOINS, EPLUS, three transmissions, sum AIK,
+      max / -min of the order counts, TDIFMUG(1..N)) ]
 (~161 KB at N=41, 81 orders: latency-bound on xGMI), which replaces the serial file-based accumulation of
 SOS_AGGREGATE (src/SOS_AGGREGATE.F:372-488).  The -ln of the three transmissions is applied after the
 reduce (SOS_AGGREGATE.F:467-488).
@@ -21,7 +22,7 @@ def shard_range(nb, rank, world):
 
 
 def pack_partial(rec, scal):
-    """rec [nseg][S][3][W], scal [nseg][8] -> one flat fp64 buffer per segment [nseg][S*3*W + 8]."""
+    """rec [nseg][S][3][W], scal [nseg][10+N] -> one flat fp64 buffer per segment [nseg][S*3*W + 10 + N]."""
     nseg = rec.shape[0]
     return torch.cat([rec.reshape(nseg, -1), scal.reshape(nseg, -1)], dim=1).contiguous()
 
@@ -29,27 +30,30 @@ def pack_partial(rec, scal):
 def unpack_partial(buf, rec_shape):
     nseg = buf.shape[0]
     n = int(np.prod(rec_shape[1:]))
-    return buf[:, :n].reshape((nseg,) + tuple(rec_shape[1:])), buf[:, n:n + 8]
+    return buf[:, :n].reshape((nseg,) + tuple(rec_shape[1:])), buf[:, n:]
 
 
-def all_reduce_partial(buf, group=None):
-    """Sum the packed partials over ranks.  Element 7 of the scalar block is max(norders): reduced
-    with MAX in a second tiny collective only when more than one rank exists."""
+def all_reduce_partial(buf, n_scal, group=None):
+    """Sum the packed partials over ranks (ONE fp64 all-reduce per band, SOS_AGGREGATE.F:372-459).  Elements 7 and 8 of
+    the scalar block (max norders, -min norders) combine with MAX in a second, two-element collective.
+    n_scal = width of the scalar block (10 + N)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return buf
-    nmax = buf[:, -1].clone()
+    o = buf.shape[1] - n_scal
+    mx = buf[:, o + 7:o + 9].clone()
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
-    buf[:, -1] = nmax
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    buf[:, o + 7:o + 9] = mx
     return buf
 
 
 def finish_scalars(scal):
-    """scal [nseg][8] (summed over all bins/ranks) -> dict of per-segment results as SOS_AGGREGATE leaves
-    them: TDIFMUS, EMOINS, EPLUS, TTOT_TRONC, TTOT_VRAI, TAUOUT, sum(AIK), n_orders."""
+    """scal [nseg][10+N] (summed over all bins/ranks) -> dict of per-segment results as SOS_AGGREGATE leaves
+    them: TDIFMUS, EMOINS, EPLUS, TTOT_TRONC, TTOT_VRAI, TAUOUT (-ln applied, SOS_AGGREGATE.F:467-488), sum(AIK),
+    n_orders, min_orders (< 0: a bin failed, the reference's IER = -1), TDIFMUG[N]."""
     s = scal.detach().cpu().numpy() if isinstance(scal, torch.Tensor) else np.asarray(scal)
     with np.errstate(divide="ignore"):
         return dict(tdifmus=s[:, 0], emoins=s[:, 1], eplus=s[:, 2], ttot_tronc=-np.log(s[:, 3]),
                     ttot_vrai=-np.log(s[:, 4]), tauout=-np.log(s[:, 5]), sum_aik=s[:, 6],
-                    n_orders=s[:, 7].astype(np.int32))
+                    n_orders=s[:, 7].astype(np.int32), min_orders=(-s[:, 8]).astype(np.int64), tdifmug=s[:, 10:])

@@ -393,10 +393,9 @@ def sos_proc(aer_phase=None, device=0, **kw):
             tauout = (1 - zzv) * h[j - 1] + zzv * h[j]                           # SOS.F:572-581
         scal = np.array([[0.0, ttot_tronc, ttot_vrai, tauout]])
         rec, sc = ctx.aggregate(out, np.ones(1), scal=scal)
-        torch.cuda.synchronize()
-        if int(out["norders"][0]) < 0:
-            raise SosProcError("SOS_OS: malformed bin")
         fin = _dist.finish_scalars(sc)
+        if int(fin["min_orders"][0]) < 0:
+            raise SosProcError("SOS_OS: malformed bin", ier=-1)
         nf = int(fin["n_orders"][0])
         tau_agg, tauout_agg = float(fin["ttot_tronc"][0]), float(fin["tauout"][0])
         ttot_vrai_agg = float(fin["ttot_vrai"][0])

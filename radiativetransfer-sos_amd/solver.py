@@ -14,6 +14,12 @@ from . import capi
 from .synth import MDF_DEFAULT
 
 
+class SosBinError(RuntimeError):
+    """A bin of the batch is malformed / needs more than CTE_OS_NT levels: the reference's IER = -1
+    (SOS_OS.F:1627-1648, SOS_PROFIL.F)."""
+    ier = -1
+
+
 def _dev_f64(x, device):
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.float64).contiguous()
@@ -168,18 +174,24 @@ class SosContext:
                    "sosgpu_profile")
         return dict(nb=nb, lp=lp, perm=None, nt=nt, iborm=iborm, prof=prof, jout=jout, zz=zz, zprof=zprof, scal=scal)
 
-    def solve_band(self, bins, aik, seg=None, group=None):
+    def solve_band(self, bins, aik, seg=None, group=None, tdifmug=None):
         """The whole per-wavelength bin loop of SOS_PROC (SOS_PROC.F:3459-3594) for bins already on the device
         (upload_bins / make_profiles): fused SOS_OS of every bin, AIK-weighted SOS_AGGREGATE, and -- when
         torch.distributed is initialised with more than one rank -- the one all-reduce that joins the ranks' bin
         slices.  aik[nb]: this rank's normalised weights (in the order of `bins`; apply bins["perm"] first when the
-        upload was cost-sorted).  Returns (rec[nseg][smax+1][3][W] device tensor, scalars dict of dist.finish_scalars)."""
+        upload was cost-sorted).  A rank may hold no bin at all (nb = 0): it contributes the neutral element.
+        Raises SosBinError (the reference's IER = -1) on every rank when any bin of the band is malformed.
+        Returns (rec[nseg][smax+1][3][W] device tensor, scalars dict of dist.finish_scalars)."""
         from . import dist as _dist
-        out = self.solve(bins)
-        rec, scal = self.aggregate(out, aik, seg=seg, scal=bins.get("scal"))
-        buf = _dist.all_reduce_partial(_dist.pack_partial(rec, scal), group=group)
+        out = self.solve(bins) if bins["nb"] else None
+        rec, scal = self.aggregate(out, aik, seg=seg, scal=bins.get("scal"), tdifmug=tdifmug)
+        buf = _dist.all_reduce_partial(_dist.pack_partial(rec, scal), scal.shape[1], group=group)
         rec, scal = _dist.unpack_partial(buf, rec.shape)
-        return rec, _dist.finish_scalars(scal)
+        fin = _dist.finish_scalars(scal)
+        if (fin["min_orders"] < 0).any():
+            raise SosBinError("SOS_OS: %d band(s) hold a malformed bin (NT outside 1..CTE_OS_NT or IBORM out of range)"
+                              % int((fin["min_orders"] < 0).sum()))
+        return rec, fin
 
     def diffuse_transmissions(self, bins):
         """Diffuse transmissions of the `-SOS.Trans` option (SOS.F:600-635): for the solar direction and for every
@@ -208,9 +220,10 @@ class SosContext:
 
     def alloc_outputs(self, nb):
         d = self.device
-        return dict(rec=torch.empty((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),
-                    norders=torch.empty(nb, dtype=torch.int32, device=d),
-                    iglast=torch.empty((nb, self.smax + 1), dtype=torch.int32, device=d),
+        # rec is zero-initialised once here: the kernel only writes the orders a bin runs (sosgpu.h)
+        return dict(rec=torch.zeros((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),
+                    norders=torch.zeros(nb, dtype=torch.int32, device=d),
+                    iglast=torch.zeros((nb, self.smax + 1), dtype=torch.int32, device=d),
                     flux=torch.zeros((nb, 2), dtype=torch.float64, device=d))
 
     def solve(self, bins, out=None):
@@ -237,19 +250,30 @@ class SosContext:
                                               _ptr(out["iglast"]), fl), "sosgpu_os_flops")
         return fl[0], fl[1]
 
-    def aggregate(self, out, aik, seg=None, scal=None):
-        """SOS_AGGREGATE over segments of bins (default: all bins = one wavelength).  Returns
-        (rec[nseg][smax+1][3][W], scal[nseg][8]) on device; see include/sosgpu.h for scal."""
-        nb = out["rec"].shape[0]
+    def aggregate(self, out, aik, seg=None, scal=None, tdifmug=None):
+        """SOS_AGGREGATE over segments of bins (default: all bins = one wavelength).  out = None or an empty batch
+        gives the neutral element (a rank without bins).  tdifmug: optional per-bin [nb][N] diffuse transmissions.
+        Returns (rec[nseg][smax+1][3][W], scal[nseg][10+N]) on device; see include/sosgpu.h for scal."""
+        nb = 0 if out is None else out["rec"].shape[0]
         d = self.device
+        sw = capi.SCAL_BASE + self.n
+        if nb == 0:
+            o_rec = torch.empty((1, self.smax + 1, 3, self.w), dtype=torch.float64, device=d)
+            o_scal = torch.empty((1, sw), dtype=torch.float64, device=d)
+            capi.check(capi.lib().sosgpu_aggregate(self._h, 0, 1, None, None, None, None, None, None, None,
+                                                   _ptr(o_rec), _ptr(o_scal), self._stream()), "sosgpu_aggregate")
+            return o_rec, o_scal
         seg_t = _dev_i32(np.array([0, nb], dtype=np.int32) if seg is None else seg, d)
         nseg = seg_t.numel() - 1
         aik_t = _dev_f64(aik, d)
         scal_t = torch.zeros((nb, 4), dtype=torch.float64, device=d) if scal is None else _dev_f64(scal, d)
+        tdg = None if tdifmug is None else _dev_f64(tdifmug, d)
+        if tdg is not None and tuple(tdg.shape) != (nb, self.n):
+            raise ValueError("tdifmug must be [nb][N]")
         o_rec = torch.empty((nseg, self.smax + 1, 3, self.w), dtype=torch.float64, device=d)
-        o_scal = torch.empty((nseg, 8), dtype=torch.float64, device=d)
+        o_scal = torch.empty((nseg, sw), dtype=torch.float64, device=d)
         capi.check(capi.lib().sosgpu_aggregate(self._h, nb, nseg, _ptr(seg_t), _ptr(aik_t), _ptr(out["rec"]),
-                                               _ptr(out["norders"]), _ptr(out["flux"]), _ptr(scal_t),
+                                               _ptr(out["norders"]), _ptr(out["flux"]), _ptr(scal_t), _ptr(tdg),
                                                _ptr(o_rec), _ptr(o_scal), self._stream()), "sosgpu_aggregate")
         return o_rec, o_scal
 

@@ -139,6 +139,72 @@ def test_malformed_bin_is_flagged_not_faulted(gpu_pkg):
     cx.close()
 
 
+def test_failed_bin_raises_in_solve_band(gpu_pkg):
+    """A malformed bin (the reference's IER = -1) must not be summed silently: solve_band raises, the aggregate skips
+    the bin and flags it, and its (never written) records are not read."""
+    import torch
+    cx, _, (h, x, y, z), aik, iborm = _batch(gpu_pkg, 4)
+    bins = cx.upload_bins(h, x, y)
+    good_rec, good_fin = cx.solve_band(bins, aik)
+    bins["nt"][2] = 40
+    out = cx.alloc_outputs(4)
+    out["rec"].fill_(float("nan"))                      # anything left unwritten must not be read
+    cx.solve(bins, out)
+    rec, sc = cx.aggregate(out, aik)
+    fin = gpu_pkg.dist.finish_scalars(sc)
+    torch.cuda.synchronize()
+    assert fin["min_orders"][0] == -1 and torch.isfinite(rec).all()
+    assert abs(fin["sum_aik"][0] - (aik.sum() - aik[2])) < 1e-15
+    with pytest.raises(gpu_pkg.SosBinError):
+        cx.solve_band(bins, aik)
+    cx.close()
+
+
+def test_empty_shard_and_tdifmug_aggregate(gpu_pkg):
+    """A rank without bins contributes the neutral element; TDIFMUG(1..N) is aggregated next to TDIFMUS
+    (SOS_AGGREGATE.F:452-459)."""
+    import torch
+    cx, _, (h, x, y, z), aik, iborm = _batch(gpu_pkg, 3)
+    rec0, sc0 = cx.aggregate(None, None)
+    torch.cuda.synchronize()
+    assert float(rec0.abs().max()) == 0.0 and float(sc0[0, :7].abs().max()) == 0.0 and float(sc0[0, 8]) < -2e9
+    out = cx.solve(cx.upload_bins(h, x, y))
+    tdg = np.random.default_rng(2).uniform(size=(3, cx.n))
+    rec, sc = cx.aggregate(out, aik, tdifmug=tdg)
+    fin = gpu_pkg.dist.finish_scalars(sc)
+    exp = np.zeros(cx.n)
+    for b in range(3):
+        exp = exp + aik[b] * tdg[b]
+    assert np.array_equal(fin["tdifmug"][0], exp)
+    cx.close()
+
+
+def test_c_abi_reduce_single_rank(gpu_pkg):
+    """sosgpu_comm_* / sosgpu_pack / sosgpu_reduce / sosgpu_unpack on a one-rank RCCL communicator: the all-reduce over
+    one rank is the identity, MAX-combined elements included."""
+    import ctypes as C
+    import torch
+    L = gpu_pkg.capi.lib()
+    cx, _, (h, x, y, z), aik, iborm = _batch(gpu_pkg, 3)
+    out = cx.solve(cx.upload_bins(h, x, y))
+    rec, sc = cx.aggregate(out, aik)
+    uid = C.create_string_buffer(128)
+    gpu_pkg.capi.check(L.sosgpu_comm_unique_id(uid), "unique_id")
+    comm = C.c_void_p()
+    gpu_pkg.capi.check(L.sosgpu_comm_init_rank(C.byref(comm), 1, uid, 0), "comm_init_rank")
+    buf = torch.empty((1, rec[0].numel() + sc.shape[1]), dtype=torch.float64, device=rec.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    gpu_pkg.capi.check(L.sosgpu_pack(cx._h, 1, p(rec), p(sc), p(buf), st), "pack")
+    gpu_pkg.capi.check(L.sosgpu_reduce(cx._h, comm, 1, p(buf), st), "reduce")
+    rec2, sc2 = torch.empty_like(rec), torch.empty_like(sc)
+    gpu_pkg.capi.check(L.sosgpu_unpack(cx._h, 1, p(buf), p(rec2), p(sc2), st), "unpack")
+    torch.cuda.synchronize()
+    assert torch.equal(rec, rec2) and torch.equal(sc, sc2)
+    gpu_pkg.capi.check(L.sosgpu_comm_destroy(comm), "comm_destroy")
+    cx.close()
+
+
 def test_diffuse_transmissions_vs_oracle(gpu_pkg, oracle):
     """-SOS.Trans (SOS.F:600-635): order-0, black-ground solves with every direction as incidence."""
     import torch
