@@ -39,6 +39,7 @@ SOS_DEFAULT_RESDOWN = "SOS_Down.txt"
 # inc/SOS.h constants used by the host-side restatements (REAL*4 literals are widened exactly as Fortran does)
 _F = lambda x: float(np.float32(x))
 CTE_OS_NBMU_MAX = 80
+CTE_LENFIC2 = 500                    # SOS.h:59
 CTE_OS_NT = 600                      # SOS.h:202
 CTE_OS_NT_MIN = 100                  # SOS.h:229
 CTE_TCOUCHE = _F(0.005)              # SOS.h:208
@@ -132,6 +133,77 @@ def set_sos_params(dict_sos, trace=True):
 
 def sos_proc_kwargs(dict_sos, trace=True):
     return dict(zip(SOS_PROC_KWARGS, set_sos_params(dict_sos, trace)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# file formats either side of the hot path
+# ---------------------------------------------------------------------------------------------------------
+def fortran_e(x, width, digits):
+    """Fortran Ew.d edit descriptor: 0.ddddddddE+ee, right-justified in `width` columns."""
+    if x == 0.0:
+        body = "0." + "0" * digits + "E+00"
+    else:
+        e = int(math.floor(math.log10(abs(x)))) + 1
+        m = abs(x) / 10.0 ** e
+        ms = "%.*f" % (digits, m)
+        if ms.startswith("1."):                  # mantissa rounded up to 1.000...: renormalise
+            e += 1
+            ms = "%.*f" % (digits, m / 10.0)
+        body = ("-" if x < 0 else "") + ms + "E%+03d" % e
+    return body.rjust(width)
+
+
+def fortran_d(x, width, digits):
+    return fortran_e(x, width, digits).replace("E", "D")
+
+
+def read_aerosols_file(path, os_nb):
+    """Parse an `Aerosols.txt` (written by SOS_AEROSOLS.F:2864-2890, read by SOS_PREPA_OS.F:666-700): truncation
+    coefficient A, truncated single-scattering albedo PIZTR (both after the ':' of their header line), three title
+    lines, then ALPHA, BETA, GAMMA, ZETA for K = 0..OS_NB (list-directed read).  PIZ = PIZTR/(1 + A (PIZTR-1)/2)
+    (SOS_PREPA_OS.F:699).  Returns the `aer_phase` dict sos_proc takes."""
+    with open(path) as f:
+        lines = f.read().splitlines()
+    if len(lines) < 8 + os_nb + 1:
+        raise SosProcError("aerosol file %s: %d coefficient rows expected" % (path, os_nb + 1))
+    a = float(lines[3].split(":", 1)[1].replace("D", "E"))
+    piztr = float(lines[4].split(":", 1)[1].replace("D", "E"))
+    rows = np.array([[float(v.replace("D", "E")) for v in lines[8 + k].split()[:4]] for k in range(os_nb + 1)])
+    return dict(alpha=rows[:, 0].copy(), beta=rows[:, 1].copy(), gamma=rows[:, 2].copy(), zeta=rows[:, 3].copy(),
+                a_tronc=a, piztr=piztr, piz=piztr / (1 + 0.5 * a * (piztr - 1)))
+
+
+def write_aerosols_file(path, aer_phase, kmat1=0.0, kmat2=0.0):
+    """`Aerosols.txt` in the layout of SOS_AEROSOLS.F:2864-2890 (formats 40-50, :3049-3056)."""
+    al, be, ga, ze = (np.asarray(aer_phase[k], dtype=np.float64) for k in ("alpha", "beta", "gamma", "zeta"))
+    a, piztr = float(aer_phase.get("a_tronc", 0.0)), float(aer_phase["piztr"])
+    with open(path, "w") as f:
+        f.write("EXTINCTION CROSS SECTION (mic^2)     :" + fortran_e(kmat1, 13, 5) + "\n")
+        f.write("SCATTERING CROSS SECTION (mic^2)     :" + fortran_e(kmat2, 13, 5) + "\n")
+        f.write("ASYMMETRY FACTOR (no truncation)     :" + fortran_e(a / 2. + (1. - a / 2.) * be[1] / 3., 13, 5) + "\n")
+        f.write("TRUNCATION COEFFICIENT               :%9.5f\n" % a)
+        f.write("SINGLE SCATTERING ALBEDO (truncation):%9.5f\n" % piztr)
+        f.write("-" * 33 + "\n")
+        f.write("PHASE MATRIX COEFFICIENTS FOR K=0 TO%4d\n" % (len(be) - 1))
+        f.write("ALPHA(K)        BETA11(K)       GAMMA12(K)      ZETA(K)\n")
+        for k in range(len(be)):
+            f.write(fortran_e(al[k], 15, 8) + "".join(" " + fortran_e(v[k], 15, 8) for v in (be, ga, ze)) + "\n")
+
+
+def write_used_angles(path, mu, ga, n0, ind_ang, nb_gauss, tetas, os_nb, os_ns, os_nm, user_file="NO_USER_ANGLES"):
+    """`SOS_UsedAngles.txt` (SOS_ANGLES.F:494-506 header, :639-647 rows `I4,1X,2D21.14,1X,I4`)."""
+    with open(path, "w") as f:
+        f.write("NB_TOTAL_ANGLES :%4d\n" % len(mu))
+        f.write("NB_GAUSS_ANGLES :%4d\n" % nb_gauss)
+        f.write("ANGLES_USERFILE :" + user_file.ljust(CTE_LENFIC2) + "\n")
+        f.write("SOLAR ZENITH ANGLE :%7.3f\n" % tetas)
+        f.write("INTERNAL_IMUS :%4d\n" % n0)
+        f.write("INTERNAL_OS_NB :%4d\n" % os_nb)
+        f.write("INTERNAL_OS_NS :%4d\n" % os_ns)
+        f.write("INTERNAL_OS_NM :%4d\n" % os_nm)
+        f.write("INDEX   COS_ANGLE            WEIGHT             USER_ANGLE\n")
+        for j in range(len(mu)):
+            f.write("%4d " % (j + 1) + fortran_d(mu[j], 21, 14) + fortran_d(ga[j], 21, 14) + " %4d\n" % ind_ang[j])
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -315,7 +387,8 @@ def sos_proc(aer_phase=None, device=0, **kw):
         raise SosProcError("-SURF.Alb must be defined")
     if p["aot_ref"] == _D:
         raise SosProcError("-AER.AOTref must be defined")
-    if p["aot_ref"] != 0.0 and aer_phase is None:
+    user_aer = str(p["ficuser_aer"]).strip()
+    if p["aot_ref"] != 0.0 and aer_phase is None and user_aer == "NO_USER_AEROSOLS":
         raise NotImplementedError("aerosol models (-AER.*: Mie, WMO, S&F, bimodal) are SURVEY 8f row f2 (next); "
                                   "pass the phase-matrix expansion through aer_phase=")
     if p["hr"] == _D:
@@ -339,7 +412,14 @@ def sos_proc(aer_phase=None, device=0, **kw):
     mu, ga, n0, ind_ang = angles(nb_lum, p["tetas"], p["ficangles_user_lum"])
     n = len(mu)
 
-    # --- aerosols: none, or given expansion (stands for SOS_AEROSOLS -> Aerosols.txt -> SOS_PREPA_OS.F:666-700)
+    # --- aerosols: none, a user Aerosols.txt (-AER.UserFile, SOS_PROC.F:2883-2934: SOS_AEROSOLS is not run, the file
+    # is read by SOS_PREPA_OS.F:666-700), or a given expansion (stands for SOS_AEROSOLS -> Aerosols.txt)
+    coef_tronca_out = None
+    if p["aot_ref"] != 0.0 and aer_phase is None:
+        if not os.path.exists(user_aer):
+            raise SosProcError("-AER.UserFile %s not found" % user_aer)
+        aer_phase = read_aerosols_file(user_aer, os_nb)
+        coef_tronca_out = 0.0          # COEF_TRONCA is an output of SOS_AEROSOLS only: untouched (0) with a user file
     if p["aot_ref"] == 0.0 or aer_phase is None:
         ta = 0.0
         alpha = beta = gamma = zeta = np.zeros(os_nb + 1)
@@ -414,7 +494,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
     return (n, ind_angout, phi_fin, theta_fin,
             up["sca"], up["i"], up["q"], up["u"], up["ang"], up["rate"], up["lpol"],
             dn["sca"], dn["i"], dn["q"], dn["u"], dn["ang"], dn["rate"], dn["lpol"],
-            tdir_vrai, flux_diff_down, flux_down, eplus, a_tronc)
+            tdir_vrai, flux_diff_down, flux_down, eplus, a_tronc if coef_tronca_out is None else coef_tronca_out)
 
 
 def write_result_bin(path, rec):

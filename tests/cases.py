@@ -196,3 +196,37 @@ def profile_case(name):
     tab = k * np.exp(-alt / hg)
     tab[0] = 0.0
     return dict(tr=tr, hr=hr, ta=ta, ha=ha, altabs=alt, tabs=tab)
+
+
+def compare_proc_outputs(rs, out, g, coef_tronca=None):
+    """run_sos.sos_proc 23-tuple against a reference SOS_PROC golden (tests/golden/sos_proc_*.npz): I,Q,U tables to 1e-9
+    relative (plus 1e-12 of the I scale for near-zero Q/U), angles / flux scalars to 1e-9; identical table shapes and fill
+    pattern.  coef_tronca: expected value of the last output when it differs from the golden's own run."""
+    assert len(out) == 23
+    n = int(g["nblum"])
+    assert out[0] == n and np.array_equal(out[1], g["ind_angout"])
+    assert out[2].shape == (361,) and out[3].shape == (81,) and out[5].shape == (361, 81)
+    assert np.allclose(out[2], g["phi"], atol=1e-12) and np.allclose(out[3], g["vza"], atol=1e-10)
+    scale = np.abs(g["i_up"]).max()
+    for k, nm in enumerate(rs.OUTPUT_NAMES):
+        if k < 4:
+            continue
+        exp = g[nm]
+        got = np.asarray(out[k])
+        if nm.startswith(("i_", "q_", "u_", "l_pol")):
+            tol = 1e-9 * np.abs(exp) + 1e-12 * scale
+            assert np.all(np.abs(got - exp) <= tol), (nm, np.abs(got - exp).max())
+        elif nm.startswith("sca_ang"):
+            # acos is ill-conditioned at exact forward/backward scattering: compare cosines tightly, angles loosely
+            assert np.allclose(np.cos(np.radians(got)), np.cos(np.radians(exp)), rtol=0, atol=1e-13), nm
+            assert np.allclose(got, exp, rtol=0, atol=1e-5), nm
+        elif nm.startswith(("pol_ang", "pol_rate")):
+            # angle/rate of polarisation are ill-conditioned where Q,U ~ 0: compare where the polarised radiance is significant
+            lp = g["l_pol_up"] if nm.endswith("up") else g["l_pol_down"]
+            m = lp > 1e-6 * scale
+            assert np.allclose(got[m], exp[m], rtol=1e-6, atol=1e-6), nm
+            assert np.array_equal(got == -999.0, exp == -999.0) or not ((got == -999.0) ^ (exp == -999.0))[m].any()
+        else:
+            if nm == "coef_tronca" and coef_tronca is not None:
+                exp = coef_tronca
+            assert abs(got - exp) <= 1e-9 * abs(exp) + 1e-15, (nm, got, exp)

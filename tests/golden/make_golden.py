@@ -126,6 +126,71 @@ def gen_sos_proc():
         print("sos_proc", name, "nblum", out[0], "i_up[0,:3]", out[5][0, :3])
 
 
+_LND = {"-AER.Model": 0, "-AER.MMD.SDtype": 1, "-AER.MMD.LNDradius": 0.30, "-AER.MMD.LNDvar": 0.60, "-AER.MMD.MRwa": 1.45,
+        "-AER.MMD.MIwa": -0.003, "-AER.MMD.MRwaref": 1.45, "-AER.MMD.MIwaref": -0.003}
+_BILND = {"-AER.Model": 3, "-AER.BMD.VCdef": 2, "-AER.BMD.RAOT": 0.4,
+          "-AER.BMD.CM.MRwa": 1.35, "-AER.BMD.CM.MIwa": -0.001, "-AER.BMD.CM.MRwaref": 1.35, "-AER.BMD.CM.MIwaref": -0.001,
+          "-AER.BMD.CM.SDradius": 0.8, "-AER.BMD.CM.SDvar": 0.6,
+          "-AER.BMD.FM.MRwa": 1.45, "-AER.BMD.FM.MIwa": -0.003, "-AER.BMD.FM.MRwaref": 1.45, "-AER.BMD.FM.MIwaref": -0.003,
+          "-AER.BMD.FM.SDradius": 0.1, "-AER.BMD.FM.SDvar": 0.46}
+_AERBASE = {"-SOS_Main.Wa": 0.550, "-ANG.Rad.NbGauss": 40, "-ANG.Aer.NbGauss": 40, "-ANG.Thetas": 35.0, "-AP.Psurf": 1013.0,
+            "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0, "-AP.AbsProfile.Type": 7, "-AER.AOTref": 0.3, "-AER.Waref": 0.550,
+            "-AER.Tronca": 1, "-SOS.IGmax": 100}
+# Aerosol-bearing end-to-end cases: the reference runs its own Mie / size-distribution / truncation
+# step and the product is fed the Aerosols.txt it wrote (through the reference's own -AER.UserFile keyword).
+PROC_AER_CASES = {
+    # BASELINE config 2 with real LND coefficients, truncation active (a_tronc != 0), 40 Gauss angles, Lambert
+    "cfg2_lnd_lambert": dict(_AERBASE, **_LND, **{"-SOS.View": 1, "-SOS.View.Phi": 30.0, "-SURF.Type": 0, "-SURF.Alb": 0.10}),
+    # BASELINE config 4: Cox-Munk 7 m/s + bimodal LND, N = 41, OS_NB = 80, polar view
+    "cfg4_glitter_bilnd": dict(_AERBASE, **_BILND, **{"-SOS.View": 2, "-SOS.View.Dphi": 60, "-SURF.Type": 1, "-SURF.Alb": 0.0,
+                                                      "-SURF.Ind": 1.34, "-SURF.Glitter.Wind": 7.0}),
+    # flat sea + LND aerosol, output at 2 km
+    "flatsea_lnd": dict(_AERBASE, **_LND, **{"-SOS.View": 1, "-SOS.View.Phi": 0.0, "-SURF.Type": 2, "-SURF.Alb": 0.02,
+                                             "-SURF.Ind": 1.34, "-SOS.OutputAlt": 2.0, "-ANG.Rad.NbGauss": 24}),
+}
+
+
+def gen_sos_proc_aer(only=None):
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    for name, user in PROC_AER_CASES.items():
+        if only and name not in only:
+            continue
+        tmp = tempfile.mkdtemp(prefix="sosproc_")
+        try:
+            u = dict(user)
+            u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF",
+                      "-SOS_Main.Log": "NO_LOG_FILE", "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE",
+                      "-SOS.Log": "SOS.Log", "-SOS.Flux": "NO_OUTPUT"})
+            p = rs.update_parameters(rs.default_parameters(), u)
+            out = R.sos_proc(list(rs.sos_proc_kwargs(p, trace=True).items()))
+            os_nb = 2 * int(user["-ANG.Aer.NbGauss"])
+            aer = rs.read_aerosols_file(os.path.join(tmp, "SOS", "Aerosols.txt"), os_nb)
+            head = open(os.path.join(tmp, "SOS", "Aerosols.txt")).read().splitlines()[:2]
+            kmat = [float(h.split(":")[1]) for h in head]
+            recs = R.read_fortran_records(os.path.join(tmp, "SOS", "SOS_Result.bin"))
+            ig = R.parse_ig_counts(open(os.path.join(tmp, "LOG", "SOS.Log"), errors="replace").read(), 100)
+            # the same run fed back through -AER.UserFile must give the same radiances (the product uses that keyword)
+            u2 = dict(u, **{"-AER.UserFile": os.path.join(tmp, "SOS", "Aerosols.txt"), "-SOS_Main.ResRoot": tmp + "/B"})
+            p2 = rs.update_parameters(rs.default_parameters(), u2)
+            out2 = R.sos_proc(list(rs.sos_proc_kwargs(p2, trace=False).items()))
+            assert np.array_equal(out[5], out2[5]) and np.array_equal(out[6], out2[6]), "user-file rerun differs"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        d = {"user_json": json.dumps(user), "result_bin": np.array(recs), "ig_counts": np.array(ig, dtype=np.int32),
+             "kmat": np.array(kmat), "coef_tronca_userfile": np.float64(out2[-1])}
+        for k, v in aer.items():
+            d["aer_" + k] = np.asarray(v)
+        for nm, v in zip(rs.OUTPUT_NAMES, out):
+            d[nm] = np.asarray(v)
+        np.savez_compressed(os.path.join(HERE, "sos_proc_%s.npz" % name), **d)
+        print("sos_proc", name, "nblum", out[0], "F", len(recs), "a_tronc", aer["a_tronc"], "coef_tronca", out[-1],
+              "userfile", out2[-1], "i_up[0,:3]", out[5][0, :3])
+
+
 def gen_aggregate():
     """SOS_AGGREGATE called once per bin in bin order (the reference appends one all-zero record per call after the
     first; those trailing records are part of the fixture)."""
@@ -160,6 +225,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "profile":
         gen_profile()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
+        gen_sos_proc_aer(sys.argv[2:])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "aggregate":
         gen_aggregate()
         sys.exit(0)
@@ -167,6 +235,7 @@ if __name__ == "__main__":
         gen_sos_os(sys.argv[1:])
         sys.exit(0)
     gen_sos_proc()
+    gen_sos_proc_aer()
     gen_glitter()
     gen_trphi()
     gen_noyaux()

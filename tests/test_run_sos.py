@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+import cases
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PROC_CASES = ["cfg1_lambert", "glitter_polar", "flatsea_zout", "nopolar_polar"]
 
@@ -74,29 +76,4 @@ def test_sos_proc_vs_reference(gpu_pkg, name):
     user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
     kw = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
     out = rs.sos_proc(**kw)
-    assert len(out) == 23
-    n = int(g["nblum"])
-    assert out[0] == n and np.array_equal(out[1], g["ind_angout"])
-    assert out[2].shape == (361,) and out[3].shape == (81,) and out[5].shape == (361, 81)
-    assert np.allclose(out[2], g["phi"], atol=1e-12) and np.allclose(out[3], g["vza"], atol=1e-10)
-    scale = np.abs(g["i_up"]).max()
-    for k, nm in enumerate(rs.OUTPUT_NAMES):
-        if k < 4:
-            continue
-        exp = g[nm]
-        got = np.asarray(out[k])
-        if nm.startswith(("i_", "q_", "u_", "l_pol")):
-            tol = 1e-9 * np.abs(exp) + 1e-12 * scale
-            assert np.all(np.abs(got - exp) <= tol), (nm, np.abs(got - exp).max())
-        elif nm.startswith("sca_ang"):
-            # acos is ill-conditioned at exact forward/backward scattering: compare cosines tightly, angles loosely
-            assert np.allclose(np.cos(np.radians(got)), np.cos(np.radians(exp)), rtol=0, atol=1e-13), nm
-            assert np.allclose(got, exp, rtol=0, atol=1e-5), nm
-        elif nm.startswith(("pol_ang", "pol_rate")):
-            # angle/rate of polarisation are ill-conditioned where Q,U ~ 0: compare where the polarised radiance is significant
-            lp = g["l_pol_up"] if nm.endswith("up") else g["l_pol_down"]
-            m = lp > 1e-6 * scale
-            assert np.allclose(got[m], exp[m], rtol=1e-6, atol=1e-6), nm
-            assert np.array_equal(got == -999.0, exp == -999.0) or not ((got == -999.0) ^ (exp == -999.0))[m].any()
-        else:
-            assert abs(got - exp) <= 1e-9 * abs(exp) + 1e-15, (nm, got, exp)
+    cases.compare_proc_outputs(rs, out, g)
