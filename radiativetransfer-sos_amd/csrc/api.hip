@@ -291,7 +291,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     if (rc) return rc;
     int per_launch = nb;
     const int lpb = sos_round_up(lp, 32);
-    const size_t per_bin = big ? sos_os_scratch_doubles(cx->d.n, lpb) : 0;
+    const size_t per_bin = big ? sos_stream_scratch_doubles(cx->d.n, lpb) : 0;
     if (big) {
         const size_t cap = ((size_t)8 << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
@@ -316,7 +316,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
-        rc = launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
+        rc = big ? launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip) : launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
         if (rc == -2) return SOSGPU_E_HIP;
         if (rc) return rc;
     }

@@ -10,8 +10,10 @@ void launch_noyaux_fetch(const SosDev &cx, int s, double *d_out, hipStream_t st)
 int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err);
 // waves / row-tiles-per-wave / column tiles / LDS bytes the solver would use (for planning and tests); <0 if unsupported.
 int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_bytes, int *big);
-// doubles of per-bin scratch the field-in-HBM variant needs for lpb levels
-size_t sos_os_scratch_doubles(int n, int lpb);
+// Streamed-field solver (sos_stream.hip) for level grids beyond the LDS-resident variants: same contract as launch_sos_os.
+// bn.scratch holds bn.scr_stride >= sos_stream_scratch_doubles(n, lpb) doubles per bin, lpb a multiple of 32.
+int launch_sos_stream(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err);
+size_t sos_stream_scratch_doubles(int n, int lpb);
 
 void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const double *d_aik,
                       const double *d_rec, const int32_t *d_norders, const double *d_flux, const double *d_scal,

@@ -22,331 +22,8 @@
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
 #include <cstdlib>
-#include <type_traits>
-#include "sos_common.h"
+#include "sos_dev.h"
 #include "kernels.h"
-
-#define SOSGPU_E_UNSUPPORTED -3
-#ifdef SOS_PROFILE_PHASES
-// s_memrealtime: constant 100 MHz counter (s_memtime is NOT wall-clock on gfx950 when waves share a SIMD: it advances
-// at 1/k of the shader clock with k MFMA-streaming waves per SIMD -- scripts/ubench_mfma_peak.hip)
-#define PH_T0() unsigned long long ph_t = __builtin_amdgcn_s_memrealtime()
-#define PH(k) do { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
-#else
-#define PH_T0() do {} while (0)
-#define PH(k) do {} while (0)
-#endif
-
-// Force a value the whole wave agrees on into scalar registers, so that the loop exits it decides are
-// uniform branches (keeps s / ig / operator pointers in SGPRs instead of per-lane VGPRs).
-__device__ __forceinline__ double uniform_f64(double v)
-{
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
-    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
-    return u.d;
-}
-__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// bitwise OR over the workgroup of up to 3 predicate bits (red: 2 x NW ints of LDS, the two halves used alternately:
-// `slot` flips on every call, so a wave that runs ahead into the next call writes the other half and ONE barrier per
-// call is enough -- the barrier also publishes whatever the caller wrote to LDS/scratch before).  No FP64 work.
-// (__syncthreads_or only returns a logical OR.)
-template <int NW>
-__device__ __forceinline__ int block_or_bits(int bits, int *red, int wv, int lane, int &slot)
-{
-    int w = 0;
-    if (__ballot(bits & 1)) w |= 1;
-    if (__ballot(bits & 2)) w |= 2;
-    if (__ballot(bits & 4)) w |= 4;
-    int *r = red + slot * NW;
-    slot ^= 1;
-    if (lane == 0) r[wv] = w;
-    __syncthreads();
-    int o = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) o |= r[i];
-    return uniform_i32(o);
-}
-
-// Instruction budget.  FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak
-// rates), and two workgroups share a CU, one wave of each per SIMD.  While one wave streams v_mfma_f64 (64 cycles
-// each, back to back) its partner gets roughly one vector-issue slot per MFMA: measured with phase stamps, every
-// non-MFMA vector instruction of the formal solution / write-back / tests costs 20-30 cycles in this regime
-// WHATEVER its kind.  The non-contraction phases are therefore written for the LOWEST VECTOR INSTRUCTION COUNT
-// (immediate offsets, wave-uniform control flow, no predicates, no divisions, no FP reductions), not for latency.
-//
-// Stop tests: "max_k |y_k| > thr" is the same decision as "exists k: |num_k| > thr |den_k|".
-// SOS_PARAM_CONV (SOS_OS.F:3434-3453): y = ((g/d - d/a) / (1 - g/d)^2) (g/x3) = (g a - d^2) d g / (a (d-g)^2 x3)
-// for a, d, x3 != 0.  (Differs from the quotient form only by rounding at the 1e-16 level of a 1e-5 threshold;
-// operands below ~1e-77 underflow in the products and are then ignored -- they are 1e-60 of the radiance scale.)
-__device__ __forceinline__ bool conv_exceeds(double a, double d, double g, double x3, double thr)
-{
-    if (a != 0.0 && d != 0.0 && x3 != 0.0) {
-        const double dg = d - g;
-        const double num = (g * a - d * d) * (d * g);
-        const double den = (a * x3) * (dg * dg);
-        return fabs(num) > thr * fabs(den);
-    }
-    return false;
-}
-// SOS_AJOUT_QUEUE (SOS_OS.F:3959-3975): g / (1 - g/d) = g d / (d - g)
-__device__ __forceinline__ double queue_term(double d, double g)
-{
-    return (d == 0.) ? 0. : (g * d) / (d - g);
-}
-
-// Field storage convention: half-system order kk = c*N + (k-1) in both direction halves, and the U component of the
-// down-going half is stored NEGATED (V- = -U(-mu)).  With that the parity combinations need no per-row sign:
-//   X^A = X+ + X-,  X^B = X+ - X-,  S+ = E^A + E^B,  S- = E^A - E^B
-// (for U: X^A_U = U+ - U-, stored S-_U = -(E^B - E^A)); the formal solution is linear with a zero boundary for
-// down-going rows, so it maps a negated source to a negated field.  The sign is restored where U(-mu) leaves the
-// field: ground values (gnd) and output records.
-//
-// Source contraction in the parity-decomposed form (sos_common.h): for both half systems
-//   acc[sys] = XDEL o (M^sys X^sys)                                              (aerosol operator, dense)
-// plus, for s <= 2, the molecular operator in its exact rank-4 form on the one half system it acts on:
-//   acc[sr] += U (YDEL o (V^T X^sr))                                             (noyaux.hip k_pack_ray)
-// A wave works on NA (1 or 2) row tiles tile0, tile0 + NW of BOTH systems x CT column tiles; bx = its B-fragment
-// base (column lane&15, k-quad lane>>4) in the field (LDS, or the HBM scratch of the BIG variants) with level stride FS.
-// Software pipeline: the A fragments (global/L2) and the raw B operands X+, X- (LDS) of k-pair m+1 are requested
-// before the 16+ MFMAs of k-pair m are issued (two register sets each, used alternately, no copies), so neither the
-// L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection of the molecular operator (RAY = half
-// system it acts on, -1 = none) either comes for free (FOLD: its four rows are packed into padding rows of the dense
-// operator) or rides in the same loop as 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
-template <int NA, int RAY, bool FOLD, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B>
-__device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
-                                            const double *__restrict__ vt, const double *__restrict__ uf,
-                                            int ks2h, int rtph, const double *bx, const double *xdel,
-                                            const double *ydel, int lane, int tile0, int prow, double *pcb)
-{
-    // fold: the projection rows V^T sit in padding rows prow..prow+3 of the packed aerosol operator (api.hip), so the
-    // dense pass below already computes V^T X^sr in the accumulator quad of those rows; pcb = this lane's slot in the
-    // (unused) padding rows of the LDS buffer through which the owning wave hands the projections to the others
-    constexpr bool fold = FOLD;          // the caller selects it: RAY >= 0, aerosol present, prow >= 0
-    struct BRaw { v2d xp[CT], xm[CT]; };
-    auto load_b = [&](BRaw &b, int m) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            b.xp[ct] = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + 8 * m);
-            b.xm[ct] = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + KHM + 8 * m);
-        }
-    };
-    const v2d *vp = reinterpret_cast<const v2d *>(vt) + lane;
-    v4d pr[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) pr[ct] = (v4d){0., 0., 0., 0.};
-    if (do_aer) {
-        const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
-        const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
-        const v2d *ap = reinterpret_cast<const v2d *>(mp) + (size_t)tile0 * rts + lane;
-        struct AFrag { v2d a[2][NA]; v2d v; };
-        auto load_a = [&](AFrag &f, int m) {
-#pragma unroll
-            for (int sy = 0; sy < 2; sy++)
-#pragma unroll
-                for (int rt = 0; rt < NA; rt++) f.a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
-            if (RAY >= 0 && !fold) f.v = vp[(size_t)m * 64];
-        };
-        auto mma = [&](const AFrag &f, const BRaw &b) {
-            v2d ba[CT], bb[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
-#pragma unroll
-            for (int rt = 0; rt < NA; rt++)
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
-                }
-#pragma unroll
-            for (int rt = 0; rt < NA; rt++)
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].y, ba[ct].y, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].y, bb[ct].y, acc[1][rt][ct], 0, 0, 0);
-                }
-            if (RAY >= 0 && !fold) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++) {
-                    const v2d bq = RAY ? bb[ct] : ba[ct];
-                    pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v.x, bq.x, pr[ct], 0, 0, 0);
-                    pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v.y, bq.y, pr[ct], 0, 0, 0);
-                }
-            }
-        };
-        AFrag f0, f1;
-        BRaw b0, b1;
-        load_a(f0, 0);
-        int m = 0;
-        if (PIPE_B) {
-            load_b(b0, 0);
-#pragma unroll 1
-            for (; m + 1 < ks2h; m += 2) {
-                load_a(f1, m + 1);
-                load_b(b1, m + 1);
-                mma(f0, b0);
-                if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
-                mma(f1, b1);
-            }
-            if (m < ks2h) mma(f0, b0);
-        } else {
-            // four column tiles: one set of B registers (32 VGPRs) -- the second set costs more in spills than it hides
-#pragma unroll 1
-            for (; m + 1 < ks2h; m += 2) {
-                load_a(f1, m + 1);
-                load_b(b0, m);
-                mma(f0, b0);
-                if (m + 2 < ks2h) load_a(f0, m + 2);
-                load_b(b0, m + 1);
-                mma(f1, b0);
-            }
-            if (m < ks2h) { load_b(b0, m); mma(f0, b0); }
-        }
-        if (fold) {
-            // accumulator register 3 of the tile holding prow is row prow + (lane>>4): the projection, in the B-operand
-            // layout of the K = 4 expansion step.  The owner publishes it and clears it (those rows are padding).
-            const int ptile = prow >> 4;
-#pragma unroll
-            for (int rt = 0; rt < NA; rt++)
-                if (tile0 + rt * NW == ptile) {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ct++) {
-                        pcb[ct * 16 * FS] = acc[RAY > 0][rt][ct][3];
-                        acc[RAY > 0][rt][ct][3] = 0.;
-                    }
-                }
-        }
-        // XDEL of the output level: every accumulator register of a lane belongs to one column
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            const double sc = xdel[ct * 16 + (lane & 15)];
-#pragma unroll
-            for (int sy = 0; sy < 2; sy++)
-#pragma unroll
-                for (int rt = 0; rt < NA; rt++) acc[sy][rt][ct] *= sc;
-        }
-    } else if (RAY >= 0) {
-        // molecular atmosphere: only the projections pr = V^T X^sr (one 16-row tile, rows 0..3 used, per column tile)
-        v2d v0 = vp[0], v1;
-        BRaw b0, b1;
-        load_b(b0, 0);
-        auto prj = [&](const v2d &v, const BRaw &b) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++) {
-                const v2d bq = RAY ? b.xp[ct] - b.xm[ct] : b.xp[ct] + b.xm[ct];
-                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, bq.x, pr[ct], 0, 0, 0);
-                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, bq.y, pr[ct], 0, 0, 0);
-            }
-        };
-        int m = 0;
-#pragma unroll 1
-        for (; m + 1 < ks2h; m += 2) {
-            v1 = vp[(size_t)(m + 1) * 64];
-            load_b(b1, m + 1);
-            prj(v0, b0);
-            if (m + 2 < ks2h) { v0 = vp[(size_t)(m + 2) * 64]; load_b(b0, m + 2); }
-            prj(v1, b1);
-        }
-        if (m < ks2h) prj(v0, b0);
-    }
-    if (RAY >= 0) {
-        if (fold) __syncthreads();             // every wave of the workgroup passes exactly one barrier here (see the call site)
-        // register 0 of pr holds row (lane>>4) in 0..3, column lane&15: exactly the B-operand layout of one
-        // K = 4 step, so the expansion U * (YDEL o pr) needs no data movement
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            const double q = (fold ? pcb[ct * 16 * FS] : pr[ct][0]) * ydel[ct * 16 + (lane & 15)];
-#pragma unroll
-            for (int rt = 0; rt < NA; rt++) {
-                const double u = uf[(size_t)(tile0 + rt * NW) * 64 + lane];
-                acc[RAY > 0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[RAY > 0][rt][ct], 0, 0, 0);
-            }
-        }
-    }
-}
-
-// Capacity constants of a variant (shared by the kernel and the host-side sizing below).
-//   KHM = rows per direction half (3N <= KHM), FS = level stride of the field, NS = row stride of the attenuation table
-__host__ __device__ constexpr int sos_khm(int nw, int rtwh) { return 16 * nw * rtwh; }
-__host__ __device__ constexpr int sos_fs(int nw, int rtwh) { return 2 * sos_khm(nw, rtwh) + 2; }
-__host__ __device__ constexpr int sos_ns(int nw, int rtwh) { return (sos_khm(nw, rtwh) / 3 + 1) & ~1; }
-
-// Formal solution of one row (SOS_INTEGR_EPOPT, SOS_OS.F:2279-2354).  With t = exp(-dtau/|mu|) and the source linear
-// in tau on the layer, both directions reduce to the same three-term recurrence
-//     X_i = t X_n + (p S_i + w S_n),   w = (1-t) |mu|/dtau - t,  p = (1-t) - w
-// evaluated as  X_i = X_n + (1-t)(S_i - X_n) + w (S_n - S_i)  with (1-t) from the per-bin table: 6 FP64 instructions per
-// level (3 of them on the dependent chain) instead of 7
-// (n = the level the ray comes from: i+1 for up-going, i-1 for down-going rows), algebraically the reference update
-// X t + (1-t)(a mu + b) -/+ a t dtau.  A block of U levels is processed in three passes so that neither the LDS
-// round trip nor the FP64 latency sits between two levels: (1) all operands of the block are loaded (the stores of
-// the block come last, so the loads cannot be held back by possible aliasing), (2) the U independent coefficient /
-// source combinations run with full instruction-level parallelism, (3) only one FMA per level is on the dependent
-// chain.  DI = -1 sweeps from level nt down to 0 (up-going rows), DI = +1 from 0 to nt; all offsets are immediates.
-// O1 = true: the source is the single-scattering source of the direct beam (SOS_FSOURCE_ORDRE1, SOS_OS.F:2557-2559, with the
-// Fresnel-reflected beam of SOS_FSOURCE_DIFF_FRESNEL1 :3280-3289 when `fres`), formed on the fly from the per-level factors
-//   S1_i = sva (ch_i XDEL_i) + svr (ch_i YDEL_i) [+ sfa (fco_i XDEL_i) + sfr (fco_i YDEL_i)]
-// (lx -> ch XDEL at the level the ray has reached; the three other level vectors follow at multiples of lstr), instead of
-// being written to the field and read back.
-struct Order1 { double sva, svr, sfa, sfr; bool fres; };
-
-template <int DI, int U, int FS, int NS, bool O1>
-__device__ __forceinline__ void scan_block(double *&q, const double *&qa, const double *&qd, double mu, double &z, double &sn,
-                                           const double *&lx, int lstr, const Order1 &o1)
-{
-    double av[U], sv[U], cv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = qa[DI * u * NS]; cv[u] = qd[DI * u]; }
-    if (O1) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) sv[u] = o1.sva * lx[DI * (u + 1)] + o1.svr * lx[lstr + DI * (u + 1)];
-        if (o1.fres) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                sv[u] = sv[u] + (o1.sfa * lx[2 * lstr + DI * (u + 1)] + o1.sfr * lx[3 * lstr + DI * (u + 1)]);
-        }
-        lx += DI * U;
-    } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) sv[u] = q[DI * (u + 1) * FS];
-    }
-    double dv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {                       // av = 1 - t (table), w = (1-t)(|mu|/dtau + 1) - 1
-        cv[u] = av[u] * (mu * cv[u] + 1.0) - 1.0;       // w
-        dv[u] = (u ? sv[u - 1] : sn) - sv[u];           // S_n - S_i
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) { z = cv[u] * dv[u] + (z + av[u] * (sv[u] - z)); cv[u] = z; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) q[DI * (u + 1) * FS] = cv[u];
-    sn = sv[U - 1];
-    q += DI * U * FS; qa += DI * U * NS; qd += DI * U;
-}
-
-// Down-going block of the field-in-HBM variant: the source of U consecutive levels is read from the LDS chunk the
-// contraction has just written (qs), the field goes straight to the scratch (q); same arithmetic as scan_block<+1>.
-template <int U, int FS, int NS>
-__device__ __forceinline__ void scan_block_split(double *&q, const double *&qs, const double *&qa, const double *&qd, double mu,
-                                                 double &z, double &sn)
-{
-    double av[U], sv[U], cv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = qa[u * NS]; cv[u] = qd[u]; sv[u] = qs[u * FS]; }
-    double dv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {                       // av = 1 - t (table), w = (1-t)(|mu|/dtau + 1) - 1
-        cv[u] = av[u] * (mu * cv[u] + 1.0) - 1.0;       // w
-        dv[u] = (u ? sv[u - 1] : sn) - sv[u];           // S_n - S_i
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) { z = cv[u] * dv[u] + (z + av[u] * (sv[u] - z)); cv[u] = z; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) q[u * FS] = cv[u];
-    sn = sv[U - 1];
-    q += U * FS; qs += U * FS; qa += U * NS; qd += U;
-}
 
 // NW   : waves per workgroup (4: N <= 42, 8: N <= 85); waves [0,NW/2) hold up-going rows, the rest down-going rows
 // RTWH : row tiles per wave and half system (tile = wave + rt*NW)

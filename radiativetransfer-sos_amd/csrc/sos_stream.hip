@@ -1,0 +1,582 @@
+// csrc/sos_stream.hip -- successive-orders solver for bins whose level grid does not fit LDS (gfx950).
+//
+// Reference profiles have NT = 100 ... 600 levels (CTE_OS_NT_MIN / CTE_OS_NT, SOS.h:229,202): the radiance field of one
+// bin, 6N rows x (NT+1) levels x 8 B, is 0.2 ... 1.2 MB at N = 41 and cannot live in the 160 KB of LDS the way the field of
+// the 30-layer benchmark bins does (sos_os.hip).  Same routine chain as sos_os.hip -- SOS_OS (src/SOS_OS.F:303-1674) with
+// SOS_FSOURCE_ORDRE1 (:2431), SOS_FSOURCE_ORDREIG (:2663), SOS_INTEGR_EPOPT (:2222), SOS_FSOURCE_DIFF_FRESNEL1 (:3106), the
+// stop tests and SOS_AJOUT_QUEUE -- with the field kept in a per-bin scratch in HBM/L2 and STREAMED through LDS in chunks
+// of 32 levels, ONE pass from the top of the atmosphere to the ground per scattering order:
+//
+//   per chunk (levels l0 .. L):   LDS-DMA (global_load_lds, 16 B/lane) of the chunk [Q+ | X-] of order ig-1
+//                                 -> X+ = Q+ + P Xin (see below) -> MFMA contraction S = M X (gemm_source, exactly the
+//                                 LDS-resident kernel's) -> formal solution of the chunk in LDS -> store [Q+ | X-] of order ig.
+//
+// The source is local in the level (S(:, i) = M X(:, i)); only the formal solution couples levels.  Down-going rows are
+// swept exactly, the running value crossing chunk borders in a register.  Up-going rows would need a second pass from the
+// ground upwards; instead the formal solution is split per chunk into its particular and homogeneous parts (a blocked scan):
+//   X+_i = Q_i + P_i Xin(c),   Q_i = solution of the chunk with zero inflow at its bottom level L,
+//   P_i = prod_{k=i}^{L-1} exp(-dtau_k/mu)  (attenuation from L up to i),   Xin(c) = X+_L,
+// with the chunk-to-chunk recurrence Xin(c-1) = A(c) + B(c) Xin(c) (A: one more layer step on Q at the top level of chunk
+// c, B = exp(-dtau_{l0-1}/mu) P_{l0}) resolved after the last chunk, when the ground value (the reflection of the previous
+// order, SOS_OS.F:1166-1239) enters.  Q is what the scratch keeps; the homogeneous part is added when the chunk is next
+// loaded.  Algebraically the reference recurrence X_i = t X_{i+1} + p S_i + w S_{i+1}; rounding differs at 1e-16 of the field.
+// Scratch traffic per scattering order: the field once in and once out (the field-in-HBM variant of round 1 moved it three
+// times, with the B operands and both sweeps latency-bound on global memory).
+#include <cstdlib>
+#include "sos_dev.h"
+#include "kernels.h"
+
+namespace {
+constexpr int COLS = 32;      // levels per chunk (two 16-column MFMA tiles)
+constexpr int VPAD = 8;       // level vectors are stored with a +1 offset (entry e = level e-1) and a few spare entries
+}
+
+// scratch of one bin, in doubles (lpb = level capacity, a multiple of COLS)
+__host__ __device__ inline size_t stream_scratch_doubles(int nw, int rtw, int lpb)
+{
+    const size_t fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw), khm = sos_khm(nw, rtw), nch = lpb / COLS;
+    const size_t d = (size_t)lpb * fs + (size_t)(lpb + 1) * ns + 7 * (size_t)(lpb + VPAD) + nch * (2 * khm + ns);
+    return (d + 15) & ~(size_t)15;
+}
+
+// Homogeneous part of the up-going field of U levels: P <- P (1 - a), X = Q + P xin (see the header); q, qa move upwards.
+template <int U, int FS, int NS>
+__device__ __forceinline__ void fix_block(double *&q, const double *&qa, double &P, double xi)
+{
+    double av[U], qv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { av[u] = qa[-u * NS]; qv[u] = q[-(u + 1) * FS]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { P = P - P * av[u]; qv[u] = qv[u] + P * xi; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[-(u + 1) * FS] = qv[u];
+    q -= U * FS; qa -= U * NS;
+}
+
+// linear LDS-DMA copy of `units` 16-byte units global -> LDS (wave-uniform LDS base + lane * 16, exec-masked tail)
+template <int NTH>
+__device__ __forceinline__ void glds_copy(const double *g, double *l, int units, int t)
+{
+    for (int u = t; u < units; u += NTH)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 2 * (size_t)u),
+                                         (__attribute__((address_space(3))) void *)(l + 2 * (size_t)(u - (t & 63))), 16, 0, 0);
+}
+
+// NW, RTWH, ZO, SURF: as k_sos_os (sos_os.hip).  Two workgroups per CU for NW = 4: while one waits for its chunk the other
+// contracts.
+template <int NW, int RTWH, bool ZO, bool SURF>
+__global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const SosDev cx, const SosBins bn)
+{
+    extern __shared__ double smem[];
+    constexpr int CT = 2, NTH = 64 * NW, HW = NW / 2;
+    constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
+    constexpr int VL = COLS + VPAD;        // chunk copy of a level vector: entry e = level (layer) l0 - 1 + e
+    const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
+    const int LPB = bn.lpb, NCH = LPB / COLS, VS = LPB + VPAD;
+    double *cbuf = smem;                   // [COLS][FS]  the chunk: field of order ig-1, then source, then field of order ig
+    double *gnd = cbuf + COLS * FS;        // [3][NS] down-going field at the ground, order ig-1
+    double *i3s = gnd + 3 * NS;            // [2][NS] I3 of the I rows (flux integrals)
+    double *red = i3s + 2 * NS;            // [16]
+    double *lga = red + 16;                // [NS] Gauss weights, [NS] mu
+    double *lmu = lga + NS;
+    double *catt = lmu + NS;               // [COLS][NS] 1 - exp(-dtau/mu): row r = layer l0 - 1 + r
+    double *cvec = catt + COLS * NS;       // [7][VL] level vectors of the chunk
+    double *cidt = cvec, *cxdel = cvec + VL, *cydel = cvec + 2 * VL, *ccxd = cvec + 3 * VL;
+    double *sbase = bn.scratch + (size_t)blockIdx.x * bn.scr_stride;
+    double *fld = sbase;                                  // [LPB][FS]
+    double *att = fld + (size_t)LPB * FS;                 // [LPB+1][NS]: row i+1 = layer i (levels i..i+1), row 0 zero
+    double *vec = att + (size_t)(LPB + 1) * NS;           // [7][VS]: idtau (layer) | xdel | ydel | cxd | cyd | fxd | fyd
+    double *xin = vec + (size_t)7 * VS;                   // [NCH][KHM]
+    double *acf = xin + (size_t)NCH * KHM;                // [NCH][KHM]
+    double *bcf = acf + (size_t)NCH * KHM;                // [NCH][NS]
+
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool up = wv < HW;               // wave-uniform
+    const int kk0 = up ? t : t - 64 * HW;
+    const bool active = kk0 < 3 * N;
+    const int kk = active ? kk0 : 0;
+    const int cj = cx.rowmap[kk];
+    const int c = cj / N;
+    const int jj = cj % N;
+    const int d = up ? jj : N + jj;
+    const int rl = up ? kk : KHM + kk;     // field row of this thread
+    const int rsv = c * 2 * N + d;
+    const double mu = cx.mu[jj];
+    const int recoff = c * W + N + (up ? (jj + 1) : -(jj + 1));
+    const size_t mper = (size_t)2 * cx.rtph * cx.ks2h * 128;
+    const int S1 = cx.smax + 1;
+    const bool tile_a = wv * 16 < KH;
+    const bool tile_b = RTWH > 1 && (wv + NW) * 16 < KH;
+    const double *bx = cbuf + (lane & 15) * FS + 2 * (lane >> 4);
+    double *pcb = cbuf + (lane & 15) * FS + (cx.prow >= 0 ? cx.prow : 0) + (lane >> 4);
+
+    const int b = blockIdx.x;
+    const int nt = uniform_i32(bn.nt[b]);
+    const int iborm = uniform_i32(bn.iborm[b]);
+    const int jout = ZO ? uniform_i32(bn.jout ? bn.jout[b] : 0) : 0;
+    const double zz = ZO ? uniform_f64(jout ? bn.zz[b] : 0.) : 0.;
+    const int jlo = (ZO && jout) ? jout - 1 : 0, jhi = (ZO && jout) ? jout : 0;
+    if (nt < 1 || nt >= LPB || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
+        if (t == 0) { bn.norders[b] = -1; bn.flux[2 * b] = 0.; bn.flux[2 * b + 1] = 0.; }
+        for (int i = t; i < cx.smax + 1; i += NTH) bn.iglast[(size_t)b * (cx.smax + 1) + i] = 0;
+        return;
+    }
+    const int nchunk = (nt + COLS) / COLS;
+    const double *pf = bn.prof + (size_t)b * 3 * bn.lp;
+    double *recb = bn.rec + (size_t)b * S1 * 3 * W;
+
+    // ---- per-bin set-up: level vectors, attenuation table, chunk link factors -> scratch -------------------------------
+    __syncthreads();
+    if (t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
+    for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
+    double *v_idt = vec, *v_xd = vec + VS, *v_yd = vec + 2 * VS, *v_cxd = vec + 3 * VS, *v_cyd = vec + 4 * VS,
+           *v_fxd = vec + 5 * VS, *v_fyd = vec + 6 * VS;
+    double *hh = v_fyd, *dtau = v_fxd;         // set-up only: these two slots end up holding the Fresnel factors
+    for (int e = t; e < VS; e += NTH) {        // entry e = level e - 1
+        const int i = e - 1;
+        const bool in = i >= 0 && i <= nt;
+        hh[e] = in ? pf[i] : 0.;
+        v_xd[e] = in ? pf[bn.lp + i] : 0.;
+        v_yd[e] = in ? pf[2 * bn.lp + i] : 0.;
+    }
+    for (int i = t; i < NS; i += NTH) att[i] = 0.;
+    // levels above nt of the last chunk stay zero in the scratch for the whole solve (they are loaded, never stored)
+    for (size_t i = (size_t)(nt + 1) * FS + t; i < (size_t)nchunk * COLS * FS; i += NTH) fld[i] = 0.;
+    __syncthreads();
+    const double htot = uniform_f64(hh[nt + 1]);
+    const double h0 = uniform_f64(hh[1]);
+    const double hlo = uniform_f64(hh[jlo + 1]), hhi = uniform_f64(hh[jhi + 1]);
+    int aer_l = 0;
+    for (int e = t; e < VS; e += NTH) {
+        const int i = e - 1;
+        const double dt = (i >= 0 && i < nt) ? hh[e + 1] - hh[e] : 0.;
+        dtau[e] = dt;
+        v_idt[e] = (i >= 0 && i < nt) ? 1.0 / dt : 0.;
+        const double ch = (i >= 0 && i <= nt) ? exp(-hh[e] / cx.mus) / 4. : 0.;                      // SOS_OS.F:837-839
+        v_cxd[e] = ch * v_xd[e]; v_cyd[e] = ch * v_yd[e];
+        if (i >= 0 && i <= nt && v_xd[e] != 0.) aer_l = 1;
+    }
+    const int has_aer = uniform_i32(__syncthreads_or(aer_l));
+    for (int i = t; i < nt * N; i += NTH)
+        att[(size_t)(i / N + 1) * NS + i % N] = 1.0 - exp(-dtau[i / N + 1] / cx.mu[i % N]);          // SOS_OS.F:2291,2335
+    __syncthreads();
+    for (int e = t; e < VS; e += NTH) {        // own elements only: h_i -> fco_i XDEL_i | fco_i YDEL_i
+        const int i = e - 1;
+        const double fco = (i >= 0 && i <= nt) ? (exp(-2. * htot / cx.mus) / 4.) * exp(hh[e] / cx.mus) : 0.;   // SOS_OS.F:3219,3278
+        v_fxd[e] = fco * v_xd[e]; v_fyd[e] = fco * v_yd[e];
+    }
+    for (int i = t; i < nchunk * N; i += NTH) {
+        // chunk cq, direction j: attenuation from the chunk's bottom level up to its top level, times the layer above it
+        const int cq = i / N, j = i % N;
+        const int l0 = cq * COLS, L = min(l0 + COLS - 1, nt);
+        double P = 1.0;
+        for (int k = L - 1; k >= l0; --k) P = P - P * att[(size_t)(k + 1) * NS + j];
+        if (cq > 0) P = P - P * att[(size_t)l0 * NS + j];                                           // layer l0 - 1
+        bcf[cq * NS + j] = P;
+    }
+    const double e_sun = uniform_f64(exp(-htot / cx.mus));
+    // ZO: attenuation from the bottom of its chunk up to the two output levels (up-going rows)
+    double plo = 1., phi = 1.;
+    if (ZO && jout && active && up) {
+        const int Llo = min((jlo / COLS) * COLS + COLS - 1, nt), Lhi = min((jhi / COLS) * COLS + COLS - 1, nt);
+        for (int k = Llo - 1; k >= jlo; --k) plo = plo - plo * att[(size_t)(k + 1) * NS + jj];
+        for (int k = Lhi - 1; k >= jhi; --k) phi = phi - phi * att[(size_t)(k + 1) * NS + jj];
+    }
+    __syncthreads();
+
+    const double usign = (c == 2 && !up) ? -1. : 1.;     // U(-mu) is stored negated (sos_dev.h, gemm_source)
+    double xb = 0., xlo = 0., xhi = 0.;
+    Order1 o1 = {0., 0., 0., 0., false};
+
+    double i4 = 0., i5 = 0.;
+    double sign = -1.;
+    int red_slot = 0;
+    int nord = 0;
+    for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
+        sign = -sign;
+        const float *rs = SURF ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
+        // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239)
+        auto ground_bc = [&]() -> double {
+            if (!(active && up)) return 0.;
+            double v = 0., xr = 0.;
+            if (c == 0 && cx.ro != 0. && s == 0) {
+                double lsol = 0.;
+#pragma unroll 1
+                for (int j = 0; j < N; j++) lsol = lsol + lga[j] * gnd[j] * lmu[j];
+                lsol = 2 * lsol * cx.ro;
+                v = lsol; xr = lsol;
+            }
+            if (SURF) {
+                double acc2 = 0.;
+                const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + jj;
+                const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + jj;
+                const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + jj;
+                const bool pol = cx.ipolar != 0;
+                constexpr int SB = 24;
+#pragma unroll 1
+                for (int j0 = 0; j0 < N; j0 += SB) {
+                    float f0[SB], f1[SB], f2[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const size_t o = (size_t)min(j0 + u, N - 1) * N;
+                        f0[u] = r0[o]; f1[u] = r1[o]; f2[u] = r2[o];
+                    }
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int j = j0 + u;
+                        if (j < N) {
+                            double q0 = f0[u], q1 = f1[u], q2 = f2[u];
+                            if (!pol) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }    // SOS_OS.F:928-941
+                            acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[NS + j] * q1 + gnd[2 * NS + j] * q2);
+                        }
+                    }
+                }
+                v = acc2 * (2 / mu) + xr;
+            }
+            if (cx.ifresnel == 1) {
+                const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
+                if (c == 0) v = v + f11 * gnd[jj] + f12 * gnd[NS + jj];
+                else if (c == 1) v = v + f12 * gnd[jj] + f11 * gnd[NS + jj];
+                else v = v + f33 * gnd[2 * NS + jj];
+            }
+            return v;
+        };
+
+        const double *svp = cx.sv + (size_t)s * 4 * KP;
+        if (active) {
+            o1.sva = svp[rsv] * usign; o1.svr = svp[KP + rsv] * usign;
+            o1.fres = cx.ifresnel == 1;
+            if (o1.fres) { o1.sfa = svp[2 * KP + rsv] * usign; o1.sfr = svp[3 * KP + rsv] * usign; }
+        }
+        double bc = 0., dirterm = 0.;
+        if (active && up) {                                                             // SOS_OS.F:970-992
+            double xr = 0.;
+            if (c == 0 && cx.ro != 0. && s == 0) { bc = cx.ro * cx.mus * e_sun; xr = bc; }
+            if (SURF) {
+                const double rr = e_sun / mu;
+                double r = rs[(size_t)(c * 3) * N * N + (size_t)(cx.n0 - 1) * N + jj];
+                if (!cx.ipolar && c) r = 0.;
+                bc = bc + r * rr;
+                dirterm = bc - xr;                                                       // SOS_OS.F:1070-1072
+            }
+        }
+        const double *mpa = cx.mp_aer + (size_t)s * mper;
+        const double *vtp = cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128;
+        const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
+        const bool fold = s <= 2 && has_aer && cx.prow >= 0;
+
+        // ---- one pass over the chunks = one scattering order (O1: the single-scattering source, formed on the fly) ----
+        auto pass = [&](auto o1_tag, double bcv) {
+            constexpr bool O1 = decltype(o1_tag)::value;
+            double dn_z = 0., dn_s = 0., up_sprev = 0., q_top = 0., qlo = 0., qhi = 0.;
+#pragma unroll 1
+            for (int chk = 0; chk < nchunk; chk++) {
+                const int l0 = chk * COLS, L = min(l0 + COLS - 1, nt), nlev = L - l0 + 1;
+                __syncthreads();                  // the previous chunk has left LDS
+                // stage the chunk: field of order ig-1 (32 levels; the scratch is zero beyond nt), attenuations of layers
+                // l0-1 .. l0+30, level vectors of levels l0-1 .. l0+38
+                if (!O1) glds_copy<NTH>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
+                glds_copy<NTH>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
+                for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + l0 + e % VL];
+                double xi = 0.;
+                if (!O1 && up && active) xi = xin[chk * KHM + kk];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!O1) {
+                    // homogeneous part of the up-going rows: X+ = Q + P Xin, P running from the bottom level upwards
+                    if (up && active) {
+                        double *q = cbuf + (size_t)(L - l0) * FS + rl;
+                        const double *qa = catt + (size_t)(L - l0) * NS + jj;      // layer L-1
+                        double P = 1.0;
+                        *q = xi;
+                        int cnt = nlev - 1;
+#pragma unroll 1
+                        for (; cnt >= 8; cnt -= 8) fix_block<8, FS, NS>(q, qa, P, xi);
+                        if (cnt & 4) fix_block<4, FS, NS>(q, qa, P, xi);
+                        if (cnt & 2) fix_block<2, FS, NS>(q, qa, P, xi);
+                        if (cnt & 1) fix_block<1, FS, NS>(q, qa, P, xi);
+                    }
+                    __syncthreads();
+                    // source function of order ig for the levels of the chunk (SOS_FSOURCE_ORDREIG)
+                    v4d acc[2][RTWH][CT];
+#pragma unroll
+                    for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                        for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                            for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
+                    auto contract = [&](auto na_tag) {
+                        constexpr int NA = decltype(na_tag)::value;
+#define SOS_GEMM(RAYV, FOLDV)                                                                                          \
+    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, true>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,            \
+                                                        cxdel + 1, cydel + 1, lane, wv, cx.prow, pcb)
+                        if (s > 2) SOS_GEMM(-1, false);
+                        else if (s & 1) { if (fold) SOS_GEMM(1, true); else SOS_GEMM(1, false); }
+                        else { if (fold) SOS_GEMM(0, true); else SOS_GEMM(0, false); }
+#undef SOS_GEMM
+                    };
+                    if (tile_b) contract(std::integral_constant<int, RTWH>());
+                    else if (tile_a) contract(std::integral_constant<int, 1>());
+                    else if (fold) __syncthreads();
+                    __syncthreads();             // every wave has read the chunk
+                    {
+                        double *wb = cbuf + (lane & 15) * FS + (lane >> 4);
+#pragma unroll
+                        for (int rt = 0; rt < RTWH; rt++) {
+                            const int tile = wv + rt * NW;
+                            const int ne = (KH - tile * 16) >> 2;
+#pragma unroll
+                            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++)
+                                    if (e < ne) {
+                                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                                        wb[ct * 16 * FS + tile * 16 + 4 * e] = ea + eb;
+                                        wb[ct * 16 * FS + KHM + tile * 16 + 4 * e] = ea - eb;
+                                    }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // formal solution of the chunk, in place (SOS_INTEGR_EPOPT)
+                if (active && !up) {
+                    double *q;
+                    const double *qa, *qd, *lx;
+                    int cnt;
+                    if (chk == 0) {               // the ray enters at the top: X-(0) = 0, S-(0) is the first "previous" source
+                        q = cbuf + rl; qa = catt + NS + jj; qd = cidt + 1; lx = ccxd + 1;
+                        dn_z = 0.;
+                        dn_s = O1 ? o1.sva * lx[0] + o1.svr * lx[VL] : *q;       // no reflected-beam term at level 0 (SOS_OS.F:3280)
+                        *q = 0.;
+                        cnt = nlev - 1;
+                    } else {
+                        q = cbuf - FS + rl; qa = catt + jj; qd = cidt; lx = ccxd; cnt = nlev;
+                    }
+#pragma unroll 1
+                    for (; cnt >= 8; cnt -= 8) scan_block<1, 8, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
+                    if (cnt & 4) scan_block<1, 4, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
+                    if (cnt & 2) scan_block<1, 2, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
+                    if (cnt & 1) scan_block<1, 1, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
+                    if (L == nt) { xb = dn_z; gnd[c * NS + jj] = xb * usign; }
+                    if (ZO && jout) {
+                        if (jlo >= l0 && jlo <= L) xlo = cbuf[(size_t)(jlo - l0) * FS + rl];
+                        if (jhi >= l0 && jhi <= L) xhi = cbuf[(size_t)(jhi - l0) * FS + rl];
+                    }
+                } else if (active) {
+                    // up-going rows: the chunk with zero inflow at its bottom level L (Q_L = 0), then the link to level l0-1
+                    double *q = cbuf + (size_t)(L - l0) * FS + rl;
+                    const double *qa = catt + (size_t)(L - l0) * NS + jj;          // layer L-1
+                    const double *qd = cidt + (L - l0);
+                    const double *lx = ccxd + (L - l0 + 1);                        // level L
+                    double sn;
+                    if (O1) {
+                        sn = o1.sva * lx[0] + o1.svr * lx[VL];
+                        if (o1.fres && L != nt) sn = sn + (o1.sfa * lx[2 * VL] + o1.sfr * lx[3 * VL]);   // SOS_OS.F:3280: none at the ground
+                    } else sn = *q;
+                    const double sbot = sn;
+                    double z = 0.;
+                    *q = 0.;
+                    int cnt = nlev - 1;
+#pragma unroll 1
+                    for (; cnt >= 8; cnt -= 8) scan_block<-1, 8, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, VL, o1);
+                    if (cnt & 4) scan_block<-1, 4, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, VL, o1);
+                    if (cnt & 2) scan_block<-1, 2, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, VL, o1);
+                    if (cnt & 1) scan_block<-1, 1, FS, NS, O1>(q, qa, qd, mu, z, sn, lx, VL, o1);
+                    if (chk == 0) q_top = z;
+                    else {
+                        // A(c): one more layer step (layer l0-1, source of level l0-1 kept from the previous chunk) on Q_l0
+                        const double a = catt[jj];
+                        const double w = a * (mu * cidt[0] + 1.0) - 1.0;
+                        acf[chk * KHM + kk] = w * (sn - up_sprev) + (z + a * (up_sprev - z));
+                    }
+                    up_sprev = sbot;
+                    if (ZO && jout) {
+                        if (jlo >= l0 && jlo <= L) qlo = cbuf[(size_t)(jlo - l0) * FS + rl];
+                        if (jhi >= l0 && jhi <= L) qhi = cbuf[(size_t)(jhi - l0) * FS + rl];
+                    }
+                }
+                __syncthreads();
+                // the chunk [Q+ | X-] of this order goes back to the scratch (levels l0..L only)
+                {
+                    const int units = nlev * FS / 2;
+                    const v2d *src = reinterpret_cast<const v2d *>(cbuf);
+                    v2d *dst = reinterpret_cast<v2d *>(fld + (size_t)l0 * FS);
+                    int u = t;
+#pragma unroll 1
+                    for (; u + 3 * NTH < units; u += 4 * NTH) {
+                        const v2d a0 = src[u], a1 = src[u + NTH], a2 = src[u + 2 * NTH], a3 = src[u + 3 * NTH];
+                        dst[u] = a0; dst[u + NTH] = a1; dst[u + 2 * NTH] = a2; dst[u + 3 * NTH] = a3;
+                    }
+#pragma unroll 1
+                    for (; u < units; u += NTH) dst[u] = src[u];
+                }
+            }
+            // after the last chunk: inflow of every chunk from the ground value upwards, Xin(c-1) = A(c) + B(c) Xin(c)
+            if (active && up) {
+                double x = bcv;
+                int cq = nchunk - 1;
+#pragma unroll 1
+                while (cq >= 1) {
+                    double av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int cc = max(cq - u, 1);
+                        av[u] = acf[cc * KHM + kk]; bv[u] = bcf[cc * NS + jj];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (cq - u >= 1) {
+                            xin[(cq - u) * KHM + kk] = x;
+                            if (ZO && jout) { if (cq - u == jlo / COLS) xlo = qlo + plo * x; if (cq - u == jhi / COLS) xhi = qhi + phi * x; }
+                            x = av[u] + bv[u] * x;
+                        }
+                    cq -= 8;
+                }
+                xin[kk] = x;
+                if (ZO && jout) { if (jlo / COLS == 0) xlo = qlo + plo * x; if (jhi / COLS == 0) xhi = qhi + phi * x; }
+                xb = q_top + bcf[jj] * x;
+            }
+        };
+
+        // ---- scattering orders ------------------------------------------------------------------------------------------
+        double i3 = 0., a1 = 0., d1 = 0., g1 = 0.;
+        double i3lo = 0., dlo = 0., i3hi = 0., dhi = 0.;
+        int ig = 1, iglast = 1;
+        for (;;) {
+            if (ig == 1) pass(std::true_type(), bc);                                 // SOS_OS.F:1025
+            else pass(std::false_type(), bc);                                        // SOS_OS.F:1157,1244
+            if (ig == 1) {                                                           // SOS_OS.F:1094-1137
+                __syncthreads();
+                i3 = xb; a1 = 0.; d1 = xb; g1 = 0.;
+                if (ZO) { i3lo = xlo; dlo = xlo; i3hi = xhi; dhi = xhi; }
+                bc = ground_bc();
+            } else {
+                g1 = xb;
+                const double i3n = i3 + g1;
+                int pm = 0;
+                if (active) {
+                    if (ig != 2 && conv_exceeds(a1, d1, g1, i3, cx.thr_cv)) pm |= 1;     // SOS_PARAM_CONV
+                    const double ag = fabs(g1);
+                    if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
+                    if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
+                }
+                pm = block_or_bits<NW>(pm, reinterpret_cast<int *>(red), wv, lane, red_slot);
+                bc = ground_bc();
+                if (ig != 2 && !(pm & 1)) {                                          // SOS_OS.F:1293-1315
+                    i3 = i3 + queue_term(d1, g1);
+                    if (ZO) { i3lo = i3lo + queue_term(dlo, xlo); i3hi = i3hi + queue_term(dhi, xhi); }
+                    break;
+                }
+                a1 = d1; d1 = g1;                                                    // SOS_OS.F:1323-1363
+                i3 = i3n;
+                if (ZO) { dlo = xlo; dhi = xhi; i3lo = i3lo + xlo; i3hi = i3hi + xhi; }
+                if (!(pm & 2)) break;                                                // SOS_OS.F:1370
+                if (!(pm & 4)) break;                                                // SOS_OS.F:1389
+                if (!(ig < cx.igmax)) break;                                         // SOS_OS.F:1406
+            }
+            ig = ig + 1;
+            if (ig > cx.igmax) break;
+            iglast = ig;
+        }
+        // SOS_OS.F:1421-1439 (see sos_os.hip: record from I3OUT - RIIOUT, tests and fluxes from I3 - RII)
+        double i3out0 = i3;
+        if (SURF && active && up) {                                                  // SOS_OS.F:1062-1084
+            const double rii = exp(-htot / mu) * dirterm;
+            const double riilo = exp(-(htot - ((ZO && jout) ? hlo : h0)) / mu) * dirterm;
+            i3out0 = i3 - riilo; i3 = i3 - rii;
+            if (ZO) {
+                const double riihi = (jout ? exp(-(htot - hhi) / mu) : 0.) * dirterm;
+                i3lo = i3lo - riilo; i3hi = i3hi - riihi;
+            }
+        }
+        if (s == 0) {                                                                // SOS_OS.F:1447-1456
+            if (active && c == 0) i3s[up ? jj : NS + jj] = i3;
+            __syncthreads();
+            if (t == 0) {
+                double em = 0., ep = 0.;
+                for (int j = 0; j < N; j++) {
+                    em = em + lmu[j] * lga[j] * i3s[NS + j];
+                    ep = ep + lmu[j] * lga[j] * i3s[j];
+                }
+                bn.flux[2 * b] = em * 2 / cx.mus;
+                bn.flux[2 * b + 1] = ep * 2 / cx.mus;
+            }
+        }
+        const double coef = (s == 0) ? 1. : 2.;                                      // SOS_OS.F:1460-1473
+        i4 = i4 + coef * i3;
+        i5 = i5 + coef * i3 * sign;
+        if (active) {                                                                // SOS_OS.F:1484-1534,1572
+            const double outv = (ZO && jout) ? ((1 - zz) * i3lo + zz * i3hi) : i3out0;
+            recb[(size_t)s * 3 * W + recoff] = outv * usign;
+            if (up && jj == 0) recb[(size_t)s * 3 * W + c * W + N] = 0.;
+        }
+        if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
+        nord = s + 1;
+        int pf2 = 0;                                                                 // SOS_ARRET_FOURIER
+        if (active) {
+            const double a3 = fabs(i3);
+            if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf2 = 1;
+        }
+        pf2 = block_or_bits<NW>(pf2, reinterpret_cast<int *>(red), wv, lane, red_slot);
+        if (!pf2) break;                                                             // SOS_OS.F:1585
+    }
+    for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
+    if (t == 0) bn.norders[b] = nord;
+}
+
+// ---------------------------------------------------------------------------------------------
+static size_t stream_lds_bytes(int nw, int rtw)
+{
+    const int fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw);
+    return ((size_t)COLS * fs + 3 * ns + 2 * ns + 16 + 2 * ns + (size_t)COLS * ns + 7 * (COLS + VPAD)) * sizeof(double);
+}
+
+static void stream_shape(int n, int *nw, int *rtw)
+{
+    const int kh = sos_round_up(3 * n, 8);
+    if (kh > 128) { *nw = 8; *rtw = 2; }
+    else { *nw = 4; *rtw = kh <= 64 ? 1 : 2; }
+}
+
+size_t sos_stream_scratch_doubles(int n, int lpb)
+{
+    int nw, rtw;
+    stream_shape(n, &nw, &rtw);
+    return stream_scratch_doubles(nw, rtw, lpb);
+}
+
+template <int NW, int RTWH, bool ZO, bool SURF>
+static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_t st, int *hip_err)
+{
+    auto kern = k_sos_stream<NW, RTWH, ZO, SURF>;
+    const size_t lds = stream_lds_bytes(NW, RTWH);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        kern<<<bn.nb, 64 * NW, lds, st>>>(cx, bn);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return -2; }
+    return 0;
+}
+
+int launch_sos_stream(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err)
+{
+    if (cx.n < 1 || cx.n > 85 || nt_max < 1 || nt_max > 1023) return SOSGPU_E_UNSUPPORTED;
+    int nw, rtw;
+    stream_shape(cx.n, &nw, &rtw);
+    if (cx.kh > sos_khm(nw, rtw) || cx.rtph * 16 < cx.kh) return SOSGPU_E_UNSUPPORTED;
+    if (!bn.scratch || bn.lpb < nt_max + 1 || bn.lpb % COLS || bn.scr_stride < stream_scratch_doubles(nw, rtw, bn.lpb))
+        return SOSGPU_E_UNSUPPORTED;
+    const int zo = bn.jout != nullptr;
+#define V(NWV, R)                                                                              \
+    if (nw == NWV && rtw == R) {                                                               \
+        if (cx.imat_surf)                                                                      \
+            return zo ? launch_stream_variant<NWV, R, true, true>(cx, bn, st, hip_err)         \
+                      : launch_stream_variant<NWV, R, false, true>(cx, bn, st, hip_err);       \
+        return zo ? launch_stream_variant<NWV, R, true, false>(cx, bn, st, hip_err)            \
+                  : launch_stream_variant<NWV, R, false, false>(cx, bn, st, hip_err);          \
+    }
+    V(4, 1) V(4, 2) V(8, 2)
+#undef V
+    return SOSGPU_E_UNSUPPORTED;
+}
