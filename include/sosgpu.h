@@ -204,6 +204,17 @@ int  sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, dou
                     double *d_prof, int32_t *d_nt, int32_t *d_iborm, double *d_zprof,
                     int32_t *d_jout, double *d_zz, double *d_scal, void *stream);
 
+/* Replaces the per-bin calls `CALL SOS_ABSPROFILE` of the CKD loop (SOS_PROC.F:3494; src/SOS_ABSPROFILE.F:184, core :325-371)
+ * for nb bins at once.  The coefficient of a gas depends on the gas, the exponential term and the layer only, so the host
+ * tabulates it once per wavelength (COEFF_ABS_CKD, src/SOS_SUB_TRS.F:171; absorption.layer_tables) and a bin is one term
+ * index per gas:
+ *   d_ik[nb][8]              1-based term index IK1..IK8 of each bin (gas order H2O, CO2, O3, N2O, CO, CH4, O2, NO2)
+ *   d_xk[8][nterm][nlev-1]   k_i of (gas, term, layer), layer 0 = top layer;  d_ro[8][nlev-1] molecules/cm2 of the layer
+ *   d_tabs[nb][nlev]         TAUABS: cumulative absorption optical depth per level, level 0 = TOA (feeds sosgpu_profile)
+ * nlev = CTE_ABS_NBLEV = 50 in the reference. */
+int  sosgpu_absprofile(int device, int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro,
+                       double *d_tabs, void *stream);
+
 /* Diagnostic hook: hand the context a device buffer [nb][8] of uint64 that builds compiled with
  * -DSOS_PROFILE_PHASES fill with per-phase cycle sums of the solver kernel (0 order-1 fill, 1 formal solution,
  * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.

@@ -442,3 +442,74 @@ def sos_aggregate(n, rec_bins, nf, aik, scal_bins):
                                         acc[2].value, 0.0])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---- gas absorption: DATATM, SOS_PREPA_ABSPROFILE, SOS_ABSPROFILE --------------------------------------
+NBABS, ABS_NBLEV, ABS_NBCOL = 8, 50, 13                       # SOS.h:246,250,254
+CKD_NWVL, CKD_NAI, CKD_NT, CKD_NP, CKD_NC = 50, 5, 9, 31, 12   # SOS.h:278-282
+
+
+def datatm(iatm, psurf=-999.0):
+    """Reference DATATM (SOS_SUB_TRS.F:908) for a predefined atmosphere IATM = 1..6: returns the profile table DONUSER
+    [50][13] (columns Z km, P hPa, T K, H2O, CO2, O3, N2O, CO, CH4, O2 in ppmv, air density; NO2/SO2 columns untouched)
+    and RO[8][50] (mass mixing ratios per level)."""
+    ro = np.zeros((NBABS, ABS_NBLEV), order="F")
+    p, t, alt, dens = (np.zeros(ABS_NBLEV) for _ in range(4))
+    don = np.zeros((ABS_NBLEV, ABS_NBCOL), order="F")
+
+    def call():
+        lib().datatm_(_p(ro), _p(p), _p(t), _p(alt), C.byref(C.c_int16(iatm)), _p(dens), _p(don),
+                      C.byref(C.c_int32(ABS_NBLEV)), C.byref(C.c_double(psurf)))
+
+    _big_stack_call(call)
+    return dict(donuser=np.ascontiguousarray(don), ro=np.ascontiguousarray(ro), p=p, t=t, alt=alt, dens=dens)
+
+
+def sos_prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil="NO_USER_ABS_PROFILE_FILE"):
+    """Reference SOS_PREPA_ABSPROFILE (SOS_PREPA_ABSPROFILE.F:248): gas amounts per layer, CKD tables of the spectral
+    file holding 1e4/wa, index LAMB1 of the interval.  SOS_ABS_ROOT must point at the tree holding fic/."""
+    os.environ.setdefault("SOS_ABS_ROOT", "/root/reference")
+    nexp = np.zeros((NBABS, CKD_NWVL), dtype=np.int32, order="F")
+    kai = np.zeros((CKD_NAI, NBABS, CKD_NWVL), order="F")
+    kki = np.zeros((CKD_NT, CKD_NP, CKD_NAI, NBABS, CKD_NWVL), order="F")
+    kh2o = np.zeros((CKD_NT, CKD_NP, CKD_NC, CKD_NAI, CKD_NWVL), order="F")
+    tab_p, tab_t, tab_c = np.zeros(CKD_NP), np.zeros(CKD_NT), np.zeros(CKD_NC)
+    nb_p, nb_t, nb_c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    iabs = np.zeros(NBABS, dtype=np.int16)
+    user = np.zeros((ABS_NBLEV, ABS_NBCOL), order="F")
+    altabs = np.zeros(ABS_NBLEV)
+    ro = np.zeros((NBABS, ABS_NBLEV), order="F")
+    nu, lamb1, ier = C.c_double(0), C.c_int32(0), C.c_int32(0)
+    d = lambda v: C.byref(C.c_double(float(v)))
+    o3c = C.c_double(float(o3))            # O3 is modified in place (Dobson -> cm.atm, SOS_PREPA_ABSPROFILE.F:547)
+
+    def call():
+        lib().sos_prepa_absprofile_(d(wa), d(nustep), d(psurf), d(h2o), C.byref(o3c), d(co2), d(ch4),
+                                    C.byref(C.c_int16(absprofil)), _fstr(ficabsprofil), C.byref(C.c_int32(0)),
+                                    C.byref(C.c_int32(99)), C.byref(nu), C.byref(lamb1), _p(iabs), _p(user), _p(altabs),
+                                    _p(ro), _p(nexp), _p(kai), _p(kki), _p(kh2o), _p(tab_p), C.byref(nb_p), _p(tab_t),
+                                    C.byref(nb_t), _p(tab_c), C.byref(nb_c), C.byref(ier), C.c_size_t(LENFIC2))
+
+    _big_stack_call(call)
+    return dict(ier=ier.value, nu=nu.value, lamb1=lamb1.value, iabs=iabs, userprofil=user, altabs=altabs, ro=ro, nexp=nexp,
+                kdis_ai=kai, kdis_ki=kki, kdis_ki_h2o=kh2o, tab_pres=tab_p, nb_pres=nb_p.value, tab_temp=tab_t,
+                nb_temp=nb_t.value, tab_conc=tab_c, nb_conc=nb_c.value)
+
+
+def sos_absprofile(prep, ik, absprofil=1):
+    """Reference SOS_ABSPROFILE (SOS_ABSPROFILE.F:184) for the exponential indices ik[8] (1-based): TAUABS(50)."""
+    tau = np.zeros(ABS_NBLEV)
+    ier = C.c_int32(0)
+    iks = [C.c_int32(int(v)) for v in ik]
+    nbp, nbt, nbc = C.c_int32(prep["nb_pres"]), C.c_int32(prep["nb_temp"]), C.c_int32(prep["nb_conc"])
+    user = np.asfortranarray(prep["userprofil"]).copy(order="F")
+
+    def call():
+        lib().sos_absprofile_(C.byref(C.c_int16(absprofil)), C.byref(C.c_double(prep["nu"])), C.byref(C.c_int32(prep["lamb1"])),
+                              _p(prep["iabs"]), _p(user), _p(prep["altabs"]), _p(prep["ro"]), _p(prep["nexp"]),
+                              _p(prep["kdis_ki"]), _p(prep["kdis_ki_h2o"]), *[C.byref(v) for v in iks],
+                              _p(prep["tab_pres"]), C.byref(nbp), _p(prep["tab_temp"]), C.byref(nbt), _p(prep["tab_conc"]),
+                              C.byref(nbc), _p(tau), C.byref(C.c_int32(0)), C.byref(C.c_int32(99)), C.byref(ier))
+
+    _big_stack_call(call)
+    return tau, ier.value

@@ -744,6 +744,19 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     return SOSGPU_OK;
 }
 
+extern "C" int sosgpu_absprofile(int device, int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk,
+                                 const double *d_ro, double *d_tabs, void *stream)
+{
+    if (nb < 1 || nlev < 2 || nlev > SOS_PROF_NBLEV_MAX || nterm < 1 || !d_ik || !d_xk || !d_ro || !d_tabs) return SOSGPU_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    launch_absprofile(nb, nlev, nterm, d_ik, d_xk, d_ro, d_tabs, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
 // Diagnostic: per-bin phase cycle counters [nb][8] (filled only by builds with -DSOS_PROFILE_PHASES).
 extern "C" int sosgpu_debug_phase_buffer(sosgpu_ctx *cx, unsigned long long *d_phase)
 {

@@ -36,3 +36,7 @@ struct ProfileArgs {
     int32_t *nt, *iborm, *jout;
 };
 void launch_profile(const ProfileArgs &a, hipStream_t st);
+
+// SOS_ABSPROFILE for nb bins: ik[nb][8] 1-based term per gas, xk[8][nterm][nlev-1], ro[8][nlev-1] -> tabs[nb][nlev]
+void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro, double *d_tabs,
+                       hipStream_t st);

@@ -308,3 +308,35 @@ void launch_profile(const ProfileArgs &a, hipStream_t st)
     const int bpw = std::min(64, std::max(1, (a.nb + 2047) / 2048));
     k_profile<<<(a.nb + bpw - 1) / bpw, 64, 0, st>>>(a, bpw);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SOS_ABSPROFILE (src/SOS_ABSPROFILE.F:325-371) for every CKD bin of a wavelength: the absorption coefficient XK of a gas
+// depends on the gas, on the exponential term chosen for it and on the layer only, so the host tabulates
+// xk[gas][term][layer] (COEFF_ABS_CKD, SOS_SUB_TRS.F:171) once and a bin is one term index per gas.  Per bin, exactly the
+// reference's loop: layer optical depth = sum over the eight gases (in order) of XK RO, transmission accumulated from the
+// top, TAUABS(level) = -ln(TRS) or CTE_TAUABS_MAX when the transmission underflows.  One thread per bin.
+// ---------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ void k_absprofile(int nb, int nlev, int nterm, const int32_t *__restrict__ ik, const double *__restrict__ xk,
+                             const double *__restrict__ ro, double *__restrict__ tabs)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int nl1 = nlev - 1;
+    int term[8];
+    for (int k = 0; k < 8; k++) term[k] = min(max(ik[8 * b + k], 1), nterm) - 1;
+    double trs = 1.0;
+    tabs[(size_t)b * nlev] = 0.;
+    for (int j = 0; j < nl1; j++) {
+        double t1c = 0.;
+        for (int k = 0; k < 8; k++) t1c = t1c + xk[((size_t)k * nterm + term[k]) * nl1 + j] * ro[(size_t)k * nl1 + j];
+        trs = trs * exp(-t1c);
+        tabs[(size_t)b * nlev + j + 1] = (trs > 0.) ? -log(trs) : 999.;            // CTE_TAUABS_MAX (SOS.h:297)
+    }
+}
+
+void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro, double *d_tabs,
+                       hipStream_t st)
+{
+    k_absprofile<<<(nb + 63) / 64, 64, 0, st>>>(nb, nlev, nterm, d_ik, d_xk, d_ro, d_tabs);
+}

@@ -367,9 +367,9 @@ def sos_proc(aer_phase=None, device=0, **kw):
     if missing:
         raise TypeError("sos_proc() missing keyword arguments: %s" % ", ".join(missing))
     p = dict(kw)
-    from .solver import SosContext
+    from .solver import SosContext, SosBinError
     from . import surface as _surface
-    from . import dist as _dist
+    from . import absorption as _abs
     import torch
 
     # --- parameter checks the hot path depends on (SOS_PROC.F:1310-2700 has many more; same messages' intent)
@@ -379,8 +379,9 @@ def sos_proc(aer_phase=None, device=0, **kw):
         raise SosProcError("-ANG.Thetas must be defined in [0,90[")
     if p["iprofil"] != 1:
         raise NotImplementedError("-AP.AerProfile.Type 2 (layer between Zmin/Zmax) is not in this round's scope")
-    if p["absprofil"] != 7:
-        raise NotImplementedError("gas absorption (CKD tables, -AP.AbsProfile.Type != 7) is SURVEY 8f row f1 (next)")
+    absprofil = int(p["absprofil"])
+    if absprofil == _I or not 0 <= absprofil <= 7:
+        raise SosProcError("-AP.AbsProfile.Type must be defined in 0..7")
     if p["isurf"] not in (0, 1, 2):
         raise NotImplementedError("land BRDF/BPDF surfaces (-SURF.Type >= 3) are SURVEY 8f row f4 (next)")
     if p["rho"] == _D:
@@ -433,16 +434,32 @@ def sos_proc(aer_phase=None, device=0, **kw):
         if p["ha"] == _D:
             raise SosProcError("-AP.AerHS.HA must be defined")
 
-    # --- molecular optical thickness and profile (SOS_PROC.F:3331-3351, 3518)
+    # --- molecular optical thickness (SOS_PROC.F:3331-3351)
     tr = p["tr"]
     if tr == _D:
         if p["psurf"] == _D:
             raise SosProcError("-AP.MOT or -AP.Psurf must be defined")
         tr = rayleigh_optical_thickness(p["wa_simu"], p["psurf"])
-    h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, p["ha"] if ta else 1.0)
-    ttot_vrai = h[-1]
-    h, xdel, ydel, iborm = rescale_profile(h, xdel, ydel, a_tronc, piz, piztr, os_nb)   # SOS.F:523-550
-    ttot_tronc = h[-1]
+    ha = p["ha"] if ta else 1.0
+    zout = float(p["zout"])
+
+    # --- gas absorption: SOS_PREPA_ABSPROFILE + the weights of the CKD bins (SOS_PROC.F:3359-3416)
+    use_gas = absprofil != 7
+    if use_gas:
+        if p["nustep"] == _I:
+            raise SosProcError("-AP.SpectralResol must be defined with -AP.AbsProfile.Type != 7")
+        if absprofil == 0 and str(p["ficabsprofil"]).strip() == "NO_USER_ABS_PROFILE_FILE":
+            raise SosProcError("-AP.AbsProfile.UserFile must be defined with -AP.AbsProfile.Type 0")
+        try:
+            prep = _abs.prepa_absprofile(p["wa_simu"], float(p["nustep"]), p["psurf"], p["h2o"], p["o3"], p["co2"], p["ch4"],
+                                         absprofil, str(p["ficabsprofil"]).strip())
+            ik, aik, _ = _abs.bins(prep)
+            xk, ro_lay = _abs.layer_tables(prep)
+        except _abs.AbsorptionError as e:
+            raise SosProcError(str(e), ier=-1)
+    mode_ckd = int(p["imode_ckd_calcul"])
+    if mode_ckd not in (1, 2):
+        raise SosProcError("-SOS.AbsModeCKD must be 1 or 2")
 
     # --- surface (SOS_PREPA_OS.F:479-497)
     isurf = int(p["isurf"])
@@ -450,6 +467,8 @@ def sos_proc(aer_phase=None, device=0, **kw):
     rsurf = None
     if isurf in (1, 2) and p["surf_ind"] == _D:
         raise SosProcError("-SURF.Ind must be defined for sea surfaces")
+    lta = ta == 0.0 or piztr == 0.0                                                  # SOS.F:541-550: IBORM = 2 without aerosols
+    iborm = min(2, os_nb) if lta else os_nb
     if isurf == 1:
         if p["wind"] == _D:
             raise SosProcError("-SURF.Glitter.Wind must be defined")
@@ -461,27 +480,61 @@ def sos_proc(aer_phase=None, device=0, **kw):
                      ifresnel=ifresnel, ind_surf=p["surf_ind"] if isurf else 1.34, ron=MDF_DEFAULT,
                      ipolar=int(p["ipolar"]), igmax=igmax, rsurf=rsurf, device=device)
     try:
-        # --- the CKD bin loop: without gas absorption there is exactly one bin of weight 1 (SOS_PROC.F:3459-3594)
-        bins = ctx.upload_bins(h[None], xdel[None], ydel[None], iborm=np.array([iborm], dtype=np.int32),
-                               zout=float(p["zout"]), zprof=zprof[None])
-        out = ctx.solve(bins)
-        if p["zout"] == -1.0:
-            tauout = h[0]                                                        # SOS.F:567-568
+        # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device, one fused solve, one aggregate
+        if not use_gas:
+            h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, ha)
+            ttot_vrai = h[-1]
+            h, xdel, ydel, ib = rescale_profile(h, xdel, ydel, a_tronc, piz, piztr, os_nb)   # SOS.F:523-550
+            bins = ctx.upload_bins(h[None], xdel[None], ydel[None], iborm=np.array([min(ib, iborm)], dtype=np.int32),
+                                   zout=zout, zprof=zprof[None])
+            if zout == -1.0:
+                tauout = h[0]                                                        # SOS.F:567-568
+            else:
+                j = int(bins["jout"][0])
+                zzv = float(bins["zz"][0])
+                tauout = (1 - zzv) * h[j - 1] + zzv * h[j]                           # SOS.F:572-581
+            bins["scal"] = np.array([[0.0, h[-1], ttot_vrai, tauout]])
+            aik = np.ones(1)
+            tabs_flux = np.zeros(_abs.NLEVEL)
         else:
-            j = int(bins["jout"][0])
-            zzv = float(bins["zz"][0])
-            tauout = (1 - zzv) * h[j - 1] + zzv * h[j]                           # SOS.F:572-581
-        scal = np.array([[0.0, ttot_tronc, ttot_vrai, tauout]])
-        rec, sc = ctx.aggregate(out, np.ones(1), scal=scal)
-        fin = _dist.finish_scalars(sc)
-        if int(fin["min_orders"][0]) < 0:
-            raise SosProcError("SOS_OS: malformed bin", ier=-1)
+            tabs = ctx.absorption_profiles(ik, xk, ro_lay)                           # SOS_ABSPROFILE of every bin
+            if mode_ckd == 2:
+                # one profile from the band-mean transmission of every level (SOS_PROC.F:3609-3676)
+                tb = tabs.cpu().numpy()
+                trs = np.zeros(tb.shape[1])
+                for b in range(tb.shape[0]):
+                    trs = trs + aik[b] * np.exp(-tb[b])
+                tabs = np.maximum(-np.log(trs), 0.0)[None]
+                aik = np.ones(1)
+            try:
+                bins = ctx.make_profiles(len(aik), tr, p["hr"], ta, ha, prep["altabs"], tabs, a_tronc=a_tronc, piz=piz,
+                                         piztr=piztr, zout=zout, absprofil=absprofil)
+            except Exception as e:
+                raise SosProcError("SOS_PROFILE: %s" % e, ier=-1)
+            tabs_flux = (tabs[-1].cpu().numpy() if hasattr(tabs, "cpu") else np.asarray(tabs)[-1])   # TAUABS of the last bin
+        tdifmug = None
+        want_trans = str(p["fictrans"]).strip() != "NO_OUTPUT"
+        if want_trans:                                                               # SOS.F:600-635
+            tdifmus_b, tdifmug = ctx.diffuse_transmissions(bins)
+            sc = bins["scal"] if hasattr(bins["scal"], "clone") else torch.from_numpy(np.asarray(bins["scal"])).to(ctx.device)
+            sc = sc.clone()
+            sc[:, 0] = tdifmus_b
+            bins["scal"] = sc
+        try:
+            rec, fin = ctx.solve_band(bins, aik, tdifmug=tdifmug)
+        except SosBinError as e:
+            raise SosProcError(str(e), ier=-1)
         nf = int(fin["n_orders"][0])
         tau_agg, tauout_agg = float(fin["ttot_tronc"][0]), float(fin["tauout"][0])
         ttot_vrai_agg = float(fin["ttot_vrai"][0])
         phi_fin, theta_fin, up, dn = trphi_tables(ctx, rec[0], nf, tau_agg, tauout_agg, itrphi, p["phios"], p["pas_phi"],
                                                   igli, p["wind"] if igli else 0.0)
         emoins, eplus = float(fin["emoins"][0]), float(fin["eplus"][0])
+        resbin = str(p["ficsos_res_bin"]).strip()
+        resroot = str(p["resroot"]).strip()
+        if resroot:                                   # SOS_PROC.F:1342-1500: results under RESROOT/SOS
+            os.makedirs(os.path.join(resroot, "SOS"), exist_ok=True)
+            write_result_bin(os.path.join(resroot, "SOS", resbin), rec[0, :nf].cpu().numpy())
     finally:
         ctx.close()
     cs = math.cos(math.pi * p["tetas"] / 180.0)
@@ -489,12 +542,57 @@ def sos_proc(aer_phase=None, device=0, **kw):
     tdir_vrai = math.exp(-ttot_vrai_agg / cs)
     flux_diff_down = emoins + tdir_tronc - tdir_vrai
     flux_down = emoins + tdir_tronc
+    if resroot and want_trans:
+        write_trans_file(os.path.join(resroot, "SOS", str(p["fictrans"]).strip()), p["tetas"], mu, tau_agg, ttot_vrai_agg,
+                         float(fin["tdifmus"][0]), fin["tdifmug"][0])
+    if resroot and str(p["ficflux"]).strip() != "NO_OUTPUT":
+        zal = prep["userprofil"][:, 0] if use_gas else np.linspace(0., 0., _abs.NLEVEL)
+        write_flux_file(os.path.join(resroot, "SOS", str(p["ficflux"]).strip()), p["tetas"], tdir_vrai, flux_diff_down, flux_down,
+                        eplus, zal, tr, p["hr"], ta, ha, tabs_flux)
     ind_angout = np.zeros(81, dtype=np.int32)
     ind_angout[:n] = ind_ang
     return (n, ind_angout, phi_fin, theta_fin,
             up["sca"], up["i"], up["q"], up["u"], up["ang"], up["rate"], up["lpol"],
             dn["sca"], dn["i"], dn["q"], dn["u"], dn["ang"], dn["rate"], dn["lpol"],
             tdir_vrai, flux_diff_down, flux_down, eplus, a_tronc if coef_tronca_out is None else coef_tronca_out)
+
+
+def write_trans_file(path, tetas, mu, ttot_tronc, ttot_vrai, tdifmus, tdifmug):
+    """-SOS.Trans file (SOS_PROC.F:3785-3822, formats 1005, 1006, 1010, 2010): direct transmission for the true optical
+    depth, diffuse transmissions brought back to the true atmosphere by + exp(-tau_tr/mu) - exp(-tau/mu)."""
+    cs = math.cos(math.pi * tetas / 180.0)
+    with open(path, "w") as f:
+        f.write("Solar Zenith Angle : %7.3f\n" % tetas)
+        f.write("Direct transmission TOA -> surface : %8.4f\n" % math.exp(-ttot_vrai / cs))
+        f.write("  \n")
+        f.write(" Diffuse transmittance : TOA -> surface\n")
+        f.write("    thetas = %6.3f   td(thetas) = %7.4f\n" % (tetas, tdifmus + math.exp(-ttot_tronc / cs) - math.exp(-ttot_vrai / cs)))
+        f.write("  \n")
+        f.write(" Diffuse transmittance : surface -> TOA\n")
+        for j in range(len(mu)):
+            td = tdifmug[j] + math.exp(-ttot_tronc / mu[j]) - math.exp(-ttot_vrai / mu[j])
+            f.write("    thetav = %6.3f   td(thetav) = %7.4f\n" % (math.degrees(math.acos(mu[j])), td))
+
+
+def write_flux_file(path, tetas, tdir_vrai, flux_diff_down, flux_down, eplus, zalt, tr, hr, ta, ha, tauabs):
+    """-SOS.Flux file (SOS_PROC.F:3840-3874, formats 1005, 2016-2020)."""
+    with open(path, "w") as f:
+        f.write("Solar Zenith Angle : %7.3f\n" % tetas)
+        f.write("  \n")
+        f.write(" Downward fluxes at BOA (normalized by TOA solar flux)\n")
+        f.write("   - Downward direct flux at BOA : %9.5f\n" % tdir_vrai)
+        f.write("   - Downward diffuse flux at BOA: %9.5f\n" % flux_diff_down)
+        f.write("   ==> Downward total flux at BOA: %9.5f\n" % flux_down)
+        f.write("  \n")
+        f.write(" Upward diffuse flux at TOA (normalized by TOA solar flux): %s\n" % repr(eplus))
+        f.write("\n\n")
+        f.write(" According to the following profile\n")
+        f.write(" Z(km)    MOT     AOT     GOT     TOTAL\n")
+        nl = len(zalt)
+        for i in range(nl - 1, -1, -1):                       # I = CTE_ABS_NBLEV .. 1; TAUABS(CTE_ABS_NBLEV+1-I)
+            z = zalt[i]
+            trz, taz, tgz = tr * math.exp(-z / hr), ta * math.exp(-z / ha), tauabs[nl - 1 - i]
+            f.write("%7.2f  %7.4f %7.4f %7.4f %7.4f\n" % (z, trz, taz, tgz, trz + taz + tgz))
 
 
 def write_result_bin(path, rec):

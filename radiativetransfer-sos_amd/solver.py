@@ -143,8 +143,23 @@ class SosContext:
         return dict(nb=nb, lp=lp, perm=perm, nt=_dev_i32(nt, d), iborm=_dev_i32(iborm, d), prof=_dev_f64(prof, d),
                     jout=None if jout is None else _dev_i32(jout, d), zz=None if zz is None else _dev_f64(zz, d))
 
+    def absorption_profiles(self, ik, xk, ro):
+        """SOS_ABSPROFILE (SOS_ABSPROFILE.F:325-371) of every CKD bin on the device (sosgpu_absprofile): ik[nb][8] 1-based
+        exponential term per gas, xk[8][nterm][nlev-1] / ro[8][nlev-1] from absorption.layer_tables.  Returns the device
+        tensor tabs[nb][nlev] that make_profiles takes."""
+        d = self.device
+        ik_t = _dev_i32(np.ascontiguousarray(ik, dtype=np.int32), d)
+        xk_t, ro_t = _dev_f64(xk, d), _dev_f64(ro, d)
+        nb, nterm, nlev = int(ik_t.shape[0]), int(xk_t.shape[1]), int(xk_t.shape[2]) + 1
+        if tuple(ik_t.shape) != (nb, 8) or xk_t.shape[0] != 8 or tuple(ro_t.shape) != (8, nlev - 1):
+            raise ValueError("ik must be [nb][8], xk [8][nterm][nlev-1], ro [8][nlev-1]")
+        tabs = torch.empty((nb, nlev), dtype=torch.float64, device=d)
+        capi.check(capi.lib().sosgpu_absprofile(d.index or 0, nb, nlev, nterm, _ptr(ik_t), _ptr(xk_t), _ptr(ro_t), _ptr(tabs),
+                                                self._stream()), "sosgpu_absprofile")
+        return tabs
+
     def make_profiles(self, nb, tr, hr, ta, ha, altabs=None, tabs=None, *, a_tronc=0.0, piz=1.0, piztr=1.0, zout=-1.0,
-                      lp=608):
+                      lp=608, absprofil=1):
         """SOS_PROFILE (IPROFIL=1) + SOS_DISC + the SOS.F rescale for nb CKD bins ON THE DEVICE (sosgpu_profile):
         tabs[nb][nblev] is each bin's cumulative gas absorption optical depth on the descending altitude grid
         altabs[nblev] (None: no gas).  Returns the same dict upload_bins returns (ready for solve()), plus `zprof` and
@@ -154,7 +169,8 @@ class SosContext:
         t_alt = t_tab = None
         nblev = 0
         if tabs is not None:
-            t_tab = _dev_f64(np.atleast_2d(np.asarray(tabs, dtype=np.float64)), d)
+            t_tab = tabs if isinstance(tabs, torch.Tensor) else np.atleast_2d(np.asarray(tabs, dtype=np.float64))
+            t_tab = _dev_f64(t_tab, d)
             t_alt = _dev_f64(np.asarray(altabs, dtype=np.float64), d)
             nblev = int(t_alt.numel())
             if t_tab.shape != (nb, nblev):
@@ -168,7 +184,7 @@ class SosContext:
         if zout != -1.0:
             jout = torch.zeros(nb, dtype=torch.int32, device=d)
             zz = torch.zeros(nb, dtype=torch.float64, device=d)
-        capi.check(capi.lib().sosgpu_profile(self._h, nb, tr, hr, ta, ha, 1, nblev, _ptr(t_alt), _ptr(t_tab),
+        capi.check(capi.lib().sosgpu_profile(self._h, nb, tr, hr, ta, ha, int(absprofil), nblev, _ptr(t_alt), _ptr(t_tab),
                                              a_tronc, piz, piztr, zout, lp, _ptr(prof), _ptr(nt), _ptr(iborm),
                                              _ptr(zprof), _ptr(jout), _ptr(zz), _ptr(scal), self._stream()),
                    "sosgpu_profile")

@@ -191,6 +191,93 @@ def gen_sos_proc_aer(only=None):
               "userfile", out2[-1], "i_up[0,:3]", out[5][0, :3])
 
 
+_CKDBASE = {"-ANG.Thetas": 35.0, "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0, "-AP.SpectralResol": 10.0, "-AP.Psurf": 1013.0,
+            "-AER.Waref": 0.550, "-SOS.IGmax": 100, "-SOS.View": 1, "-SOS.View.Phi": 40.0}
+# Multi-bin CKD bands: the reference's own CKD tables under /root/reference/fic.
+PROC_CKD_CASES = {
+    # O2-A band, 0.762 um, mid-latitude summer: 5 bins (O2), Rayleigh only, Lambert
+    "ckd_o2a_5bins": dict(_CKDBASE, **{"-SOS_Main.Wa": 0.762, "-ANG.Rad.NbGauss": 16, "-AP.AbsProfile.Type": 2, "-AER.AOTref": 0.0,
+                                       "-SURF.Type": 0, "-SURF.Alb": 0.20, "-SOS.Trans": "SOS_Transm.txt", "-SOS.Flux": "Flux.txt"}),
+    # BASELINE config 3 shape: H2O x O2 band at 15925 cm-1 (25 bins), tropical atmosphere with user H2O / O3 amounts,
+    # LND aerosol, polarised, flat sea
+    "ckd_h2o_o2_25bins_flatsea": dict(_CKDBASE, **_LND, **{"-SOS_Main.Wa": 1.0e4 / 15925.0, "-ANG.Rad.NbGauss": 24,
+                                                          "-ANG.Aer.NbGauss": 40, "-AP.AbsProfile.Type": 1, "-AP.H2O": 2.5,
+                                                          "-AP.O3": 310.0, "-AER.AOTref": 0.2, "-AER.Waref": 1.0e4 / 15925.0,
+                                                          "-AER.Tronca": 1, "-SURF.Type": 2, "-SURF.Alb": 0.0, "-SURF.Ind": 1.34}),
+    # the single-profile shortcut -SOS.AbsModeCKD 2 on the O2-A band, US standard atmosphere, output at 3 km
+    "ckd_o2a_mode2": dict(_CKDBASE, **{"-SOS_Main.Wa": 0.762, "-ANG.Rad.NbGauss": 16, "-AP.AbsProfile.Type": 6, "-AER.AOTref": 0.0,
+                                       "-SURF.Type": 0, "-SURF.Alb": 0.05, "-SOS.AbsModeCKD": 2, "-SOS.OutputAlt": 3.0,
+                                       "-AP.CO2": 410.0, "-AP.CH4": 1.9}),
+}
+
+
+def gen_sos_proc_ckd(only=None):
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    os.environ["SOS_ABS_ROOT"] = "/root/reference"
+    for name, user in PROC_CKD_CASES.items():
+        if only and name not in only:
+            continue
+        tmp = tempfile.mkdtemp(prefix="sosproc_")
+        try:
+            u = dict(user)
+            u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF",
+                      "-SOS_Main.Log": "NO_LOG_FILE", "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE", "-SOS.Log": "NO_LOG_FILE"})
+            u.setdefault("-SOS.Flux", "NO_OUTPUT")
+            p = rs.update_parameters(rs.default_parameters(), u)
+            out = R.sos_proc(list(rs.sos_proc_kwargs(p, trace=False).items()))
+            d = {"user_json": json.dumps(user), "result_bin": np.array(R.read_fortran_records(os.path.join(tmp, "SOS", "SOS_Result.bin")))}
+            if user["-AER.AOTref"] != 0.0:
+                os_nb = 2 * int(user["-ANG.Aer.NbGauss"])
+                aer = rs.read_aerosols_file(os.path.join(tmp, "SOS", "Aerosols.txt"), os_nb)
+                head = open(os.path.join(tmp, "SOS", "Aerosols.txt")).read().splitlines()[:2]
+                d["kmat"] = np.array([float(h.split(":")[1]) for h in head])
+                for k, v in aer.items():
+                    d["aer_" + k] = np.asarray(v)
+            for key in ("-SOS.Trans", "-SOS.Flux"):
+                if user.get(key, "NO_OUTPUT") != "NO_OUTPUT":
+                    d["file" + key[4:].lower().replace(".", "_")] = open(os.path.join(tmp, "SOS", user[key])).read()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        for nm, v in zip(rs.OUTPUT_NAMES, out):
+            d[nm] = np.asarray(v)
+        np.savez_compressed(os.path.join(HERE, "sos_proc_%s.npz" % name), **d)
+        print("sos_proc", name, "nblum", out[0], "F", len(d["result_bin"]), "i_up[0,:3]", out[5][0, :3], "fluxes", out[18:22])
+
+
+ABS_CASES = {      # name: (wa, nustep, psurf, h2o, o3, co2, ch4, type)
+    "o2a_mls": (0.762, 10.0, 1013.0, -999., -999., -999., -999., 2),
+    "h2o_o2_trop_user": (1.0e4 / 15925.0, 10.0, 980.0, 2.5, 310.0, 400.0, 1.8, 1),
+    "h2o_o2_subarctic": (1.0e4 / 15925.0, 10.0, 1013.0, -999., 280.0, -999., -999., 4),
+    "o2a_us62_nopsurf": (0.762, 10.0, -999.0, 1.0, -999., -999., -999., 6),
+}
+
+
+def gen_absorption():
+    """SOS_PREPA_ABSPROFILE + SOS_ABSPROFILE of the compiled reference (full CKD tables): layer amounts, interval index,
+    weights and TAUABS(50) of EVERY bin in the reference's loop order."""
+    import importlib
+    ckd = importlib.import_module("radiativetransfer-sos_amd.ckd")
+    os.environ["SOS_ABS_ROOT"] = "/root/reference"
+    d = {}
+    for name, (wa, nustep, psurf, h2o, o3, co2, ch4, typ) in ABS_CASES.items():
+        r = R.sos_prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, typ)
+        assert r["ier"] == 0
+        iw = r["lamb1"] - 1
+        nexp = r["nexp"][:, iw].copy()
+        ik, aik, ssum = ckd.ckd_bin_weights(nexp, r["kdis_ai"][:, :, iw])
+        tau = np.array([R.sos_absprofile(r, k, typ)[0] for k in ik])
+        for key, v in dict(args=np.array([wa, nustep, psurf, h2o, o3, co2, ch4, typ]), nu=r["nu"], lamb1=r["lamb1"],
+                           altabs=r["altabs"], userprofil=r["userprofil"], ro=r["ro"], nexp=nexp, kdis_ai=r["kdis_ai"][:, :, iw],
+                           ik=ik, tau=tau).items():
+            d[name + "_" + key] = np.asarray(v)
+        print("absorption", name, "lamb1", r["lamb1"], "nexp", list(nexp), "tau_tot", tau[:, -1].min(), tau[:, -1].max())
+    np.savez_compressed(os.path.join(HERE, "absorption.npz"), **d)
+
+
 def gen_aggregate():
     """SOS_AGGREGATE called once per bin in bin order (the reference appends one all-zero record per call after the
     first; those trailing records are part of the fixture)."""
@@ -228,6 +315,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "absorption":
+        gen_absorption()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "proc_ckd":
+        gen_sos_proc_ckd(sys.argv[2:])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "aggregate":
         gen_aggregate()
         sys.exit(0)
@@ -236,6 +329,8 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_sos_proc()
     gen_sos_proc_aer()
+    gen_sos_proc_ckd()
+    gen_absorption()
     gen_glitter()
     gen_trphi()
     gen_noyaux()
