@@ -49,7 +49,7 @@ def test_prepa_and_absprofile_vs_reference(pkg, fic, name):
     ref = g[name + "_tau"]
     for b in range(len(ik)):
         tau = A.absprofile_host(xk, ro, ik[b])
-        assert np.all(np.abs(tau - ref[b]) <= 1e-13 * ref[b, -1]), (name, b)
+        assert np.all(np.abs(tau - ref[b]) <= 2e-15 + 1e-13 * ref[b, -1]), (name, b)
 
 
 def test_bin_order_and_weights_are_the_reference_loop_nest(pkg):
@@ -124,8 +124,8 @@ def test_absprofile_kernel_vs_host(gpu_pkg, fic):
         ref = g[name + "_tau"]
         for b in range(len(ik)):
             host = A.absprofile_host(xk, ro, ik[b])
-            assert np.all(np.abs(tabs[b] - host) <= 1e-14 * host[-1]), (name, b)
-            assert np.all(np.abs(tabs[b] - ref[b]) <= 1e-13 * ref[b, -1]), (name, b)
+            assert np.all(np.abs(tabs[b] - host) <= 2e-15 + 1e-14 * host[-1]), (name, b)       # -ln(TRS) near TRS = 1
+            assert np.all(np.abs(tabs[b] - ref[b]) <= 2e-15 + 1e-13 * ref[b, -1]), (name, b)
     cx.close()
 
 

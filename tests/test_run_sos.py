@@ -50,17 +50,19 @@ def test_host_restatements_against_reference_outputs(pkg):
     assert abs(h[-1] - 0.3948) < 1e-8 and np.all(np.diff(h) > 0) and np.allclose(xdel[1:] + ydel[1:], 1.0, atol=1e-7)
 
 
-def test_sos_proc_rejects_out_of_scope(pkg):
+def test_sos_proc_rejects_bad_or_unsupported_parameters(pkg):
     rs = pkg.run_sos
-    kw = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), {
-        "-SOS_Main.Wa": 0.55, "-ANG.Thetas": 30.0, "-AP.AbsProfile.Type": 2, "-AER.AOTref": 0.0, "-SURF.Alb": 0.1,
-        "-AP.HR": 8.0, "-SOS.View": 1, "-SOS.View.Phi": 0.0}))
-    with pytest.raises(NotImplementedError):
-        rs.sos_proc(**kw)
-    kw["absprofil"] = 7
-    kw["aot_ref"] = 0.3
-    with pytest.raises(NotImplementedError):
-        rs.sos_proc(**kw)
+    base = {"-SOS_Main.Wa": 0.55, "-ANG.Thetas": 30.0, "-AP.AbsProfile.Type": 7, "-AER.AOTref": 0.0, "-SURF.Alb": 0.1,
+            "-AP.HR": 8.0, "-SOS.View": 1, "-SOS.View.Phi": 0.0}
+    kw = lambda **over: rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), dict(base, **over)))
+    with pytest.raises(rs.SosProcError):                       # gas absorption needs the spectral resolution of the CKD tables
+        rs.sos_proc(**kw(**{"-AP.AbsProfile.Type": 2, "-AP.Psurf": 1013.0}))
+    with pytest.raises(rs.SosProcError):
+        rs.sos_proc(**kw(**{"-AP.AbsProfile.Type": 9}))
+    with pytest.raises(NotImplementedError):                   # aerosol models without a phase-matrix file
+        rs.sos_proc(**kw(**{"-AER.AOTref": 0.3}))
+    with pytest.raises(NotImplementedError):                   # aerosol layer profile (reference output not reproducible)
+        rs.sos_proc(**kw(**{"-AP.AerProfile.Type": 2}))
     with pytest.raises(TypeError):
         rs.sos_proc(wa_simu=0.55)
 
