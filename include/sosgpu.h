@@ -72,8 +72,9 @@ int  sosgpu_destroy(sosgpu_ctx *cx);
 
 /* Surface reflection matrices for imat_surf=1: REAL*4, reference FICSURF record order
  * d_rsurf[s][ab][(J-1)*N+(I-1)] = R_ab(I,J), s = 0..iborm_max (SOS_OS.F:916-925).  Device pointer; the call
- * copies the matrices into the context (transposed, so that the rows k of a wavefront read consecutive floats) and
- * synchronises the device -- the caller may release d_rsurf afterwards. */
+ * packs them into the context as FP64 ground-reflection operators in matrix-core fragment order (weights, 2/mu and the
+ * Lambertian part folded in) and synchronises the device -- the caller may release d_rsurf afterwards.  Call it after
+ * sosgpu_create and before sosgpu_os_solve. */
 int  sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf);
 
 /* Replaces SOS_NOYAUX (SOS_OS.F:1857-2158) for every Fourier order 0..iborm_max at once; must be called

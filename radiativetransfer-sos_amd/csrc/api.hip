@@ -35,7 +35,7 @@ struct sosgpu_ctx {
     double *agg_partial;    // chunk partials of the large-batch aggregate
     double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
     double *prof_ng;        // [4][608] no-gas profile of the wavelength (sosgpu_profile)
-    float *rsurf_t;         // transposed copy of the caller's surface matrices (context-owned)
+    double *gnd_op, *gnd_dir;   // packed ground-reflection operators / solar-beam columns of the surface matrices (context-owned)
     size_t scratch_doubles;
 };
 
@@ -99,7 +99,8 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->phase = nullptr;
     cx->agg_partial = nullptr;
     cx->prof_ng = nullptr;
-    cx->rsurf_t = nullptr;
+    cx->gnd_op = nullptr;
+    cx->gnd_dir = nullptr;
     SosDev &d = cx->d;
     memset(&d, 0, sizeof(d));
     d.n = N; d.w = 2 * N + 1; d.r6 = 6 * N;
@@ -219,32 +220,59 @@ extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
 
 extern "C" size_t sosgpu_ctx_bytes(const sosgpu_ctx *cx) { return cx ? cx->bytes : 0; }
 
-// rt[s][ab][j][k] = r[s][ab][k][j]: the solver reads, for an up-going row k, the matrix column over the incident
-// directions j -- with the transposed copy consecutive lanes (rows k) read consecutive floats.
-__global__ void k_transpose_surface(int n, size_t nmat, const float *__restrict__ r, float *__restrict__ rt)
+// Ground-reflection operator of a BRDF/BPDF surface in the packed A-fragment layout of the source operators (one system,
+// rows = up-going half-system positions (c, k), columns = down-going positions (b, j), sos_common.h):
+//   G[(c,k)][(b,j)] = (2/mu_k) w_j R_cb(j, k)   (SOS_OS.F:1194-1220; R_cb(I = j, J = k) = r[s][c*3+b][k*N + j])
+//                     + 2 rho w_j mu_j for c = b = 0 and s = 0 (Lambertian part, SOS_OS.F:1177-1190)
+// with the polarisation cut of SOS_OS.F:928-941 (IPOLAR = 0: only R_11 is kept), plus the solar-beam column
+// rdir[s][c][k] = R_c1(N0, k) of the direct term (SOS_OS.F:984-990).
+__global__ void k_pack_ground(SosDev cx, const float *__restrict__ r, double *__restrict__ gop, double *__restrict__ rdir)
 {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nmat * n * n) return;
-    const size_t mat = e / ((size_t)n * n);
-    const int j = (int)((e / n) % n), k = (int)(e % n);
-    rt[e] = r[mat * n * n + (size_t)k * n + j];
+    const int s = blockIdx.y, N = cx.n;
+    const size_t per = (size_t)cx.rtph * cx.ks2h * 128;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *rs = r + (size_t)s * 9 * N * N;
+    if (q < per) {
+        const int e2 = q & 1, lane = (q >> 1) & 63;
+        const int m = (int)((q >> 7) % cx.ks2h), rt = (int)((q >> 7) / cx.ks2h);
+        const int row = rt * 16 + (lane & 15), col = 8 * m + 2 * (lane >> 4) + e2;
+        double v = 0.;
+        if (row < 3 * N && col < 3 * N) {
+            const int ro = cx.rowmap[row], co = cx.rowmap[col];
+            const int c = ro / N, k = ro % N, b = co / N, j = co % N;
+            double x = rs[(size_t)(c * 3 + b) * N * N + (size_t)k * N + j];
+            if (!cx.ipolar && (c || b)) x = 0.;
+            v = (2. / cx.mu[k]) * cx.ga[j] * x;
+            if (c == 0 && b == 0 && s == 0 && cx.ro != 0.) v = v + 2. * cx.ro * cx.ga[j] * cx.mu[j];
+        }
+        gop[(size_t)s * per + q] = v;
+    }
+    if (q < (size_t)3 * N) {
+        const int c = (int)(q / N), k = (int)(q % N);
+        double x = rs[(size_t)(c * 3) * N * N + (size_t)k * N + (cx.n0 - 1)];
+        if (!cx.ipolar && c) x = 0.;
+        rdir[(size_t)s * 3 * N + q] = x;
+    }
 }
 
 extern "C" int sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf)
 {
     if (!cx) return SOSGPU_E_ARG;
     if (cx->d.imat_surf && !d_rsurf) return SOSGPU_E_ARG;
-    if (!d_rsurf) { cx->d.rsurf = nullptr; return SOSGPU_OK; }
+    if (!d_rsurf) { cx->d.mp_gnd = nullptr; cx->d.rdir = nullptr; return SOSGPU_OK; }
     HIPCHK(hipSetDevice(cx->device));
-    const size_t nmat = (size_t)(cx->d.smax + 1) * 9, cnt = nmat * cx->d.n * cx->d.n;
-    if (!cx->rsurf_t) {
-        int rc = dev_alloc(cx, &cx->rsurf_t, cnt);
+    const size_t per = (size_t)cx->d.rtph * cx->d.ks2h * 128, S1 = (size_t)cx->d.smax + 1;
+    if (!cx->gnd_op) {
+        int rc = dev_alloc(cx, &cx->gnd_op, S1 * per);
+        if (!rc) rc = dev_alloc(cx, &cx->gnd_dir, S1 * 3 * cx->d.n);
         if (rc) return rc;
     }
-    k_transpose_surface<<<(unsigned)((cnt + 255) / 256), 256>>>(cx->d.n, nmat, d_rsurf, cx->rsurf_t);
+    dim3 grid((unsigned)((std::max(per, (size_t)3 * cx->d.n) + 255) / 256), (unsigned)S1);
+    k_pack_ground<<<grid, 256>>>(cx->d, d_rsurf, cx->gnd_op, cx->gnd_dir);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());          // the caller may release or overwrite d_rsurf afterwards
-    cx->d.rsurf = cx->rsurf_t;
+    cx->d.mp_gnd = cx->gnd_op;
+    cx->d.rdir = cx->gnd_dir;
     return SOSGPU_OK;
 }
 
@@ -278,7 +306,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     if (!cx || nb < 0 || lp < 2 || !d_nt || !d_iborm || !d_prof || !d_rec || !d_norders || !d_iglast || !d_flux)
         return SOSGPU_E_ARG;
     if ((d_jout == nullptr) != (d_zz == nullptr)) return SOSGPU_E_ARG;
-    if (cx->d.imat_surf && !cx->d.rsurf) return SOSGPU_E_ARG;
+    if (cx->d.imat_surf && !cx->d.mp_gnd) return SOSGPU_E_ARG;
     if (nb == 0) return SOSGPU_OK;
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;

@@ -49,7 +49,11 @@ struct SosDev {                 // per-wavelength device context, passed by valu
     double *mp_vt;              // [3][ks2h*128]  molecular operator, projection factor V^T (one 16-row tile, rows 0..3 used)
     double *mp_uf;              // [3][rtph*64]   molecular operator, expansion factor U (K = 4)
     double *sv;                 // [smax+1][4][kp]: order-1 vectors aer, ray, fresnel-aer, fresnel-ray
-    const float *rsurf;         // [smax+1][9][N j][N k] TRANSPOSED surface matrices R_ab(k <- j) (api.hip), or null
+    // BRDF/BPDF surface (IMAT_SURF = 1), built by sosgpu_set_surface_matrices (api.hip k_pack_ground), or null:
+    const double *mp_gnd;       // [smax+1][rtph*ks2h*128] ground-reflection operator G_s in the packed A-fragment layout of
+                                // mp_aer (one system): G[(c,k)][(b,j)] = (2/mu_k) w_j R_cb(j -> k) (+ 2 rho w_j mu_j for
+                                // c = b = 0, s = 0: the Lambertian part), rows / columns in half-system order
+    const double *rdir;         // [smax+1][3][N] R_c1(N0, k): reflection of the direct solar beam (SOS_OS.F:984-990)
 };
 
 struct SosBins {

@@ -28,11 +28,8 @@
 // NW   : waves per workgroup (4: N <= 42, 8: N <= 85); waves [0,NW/2) hold up-going rows, the rest down-going rows
 // RTWH : row tiles per wave and half system (tile = wave + rt*NW)
 // CT   : column tiles (16 levels each) held in LDS at once
-// BIG = false: the whole field (NT+1 <= 16*CT levels) lives in LDS.
-// BIG = true : the field, the attenuation table and the level vectors live in a per-bin HBM/L2 scratch
-//              (reference profiles have NT = 100..600, SOS.h:202,229); the contraction runs over chunks of 16*CT levels
-//              reading its B operands from the scratch, the source chunk lands in LDS: the down-going rows are swept from
-//              it right away, S+ is copied out and the up-going rows are swept after the last chunk.
+// The whole field (NT+1 <= 16*CT levels) lives in LDS; larger level grids (reference profiles have NT = 100..600,
+// SOS.h:202,229) run in sos_stream.hip, which streams the field through LDS chunk by chunk.
 // SURF = true: BRDF/BPDF reflection matrices (IMAT_SURF = 1, SOS_OS.F:912-925); a template argument because its per-row
 //             matrix pointers and direct-beam terms otherwise stay live across the contraction (30 spilled VGPRs, -2.6 %)
 // ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- two extra levels per row are
@@ -41,7 +38,7 @@
 // form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded form with a few
 // scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one instantiation gave wrong down-going rows on
 // gfx950, so it is not used.
-template <int NW, int RTWH, int CT, bool BIG, bool ZO, bool SURF>
+template <int NW, int RTWH, int CT, bool ZO, bool SURF>
 __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
@@ -49,16 +46,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
     constexpr int COLS = 16 * CT;
     constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
     const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
-    const int LPB = BIG ? bn.lpb : COLS;   // level capacity of the field storage
-    double *cbuf = smem;                   // [COLS][FS]  LDS: the field itself, or the source chunk (BIG)
-    double *gnd = cbuf + COLS * FS;        // [3][NS] down-going field at the ground, order ig-1
-    double *i3s = gnd + 3 * NS;            // [2][NS] I3 of the I rows (flux integrals)
-    double *red = i3s + 2 * NS;            // [16]
-    double *lga = red + 16;                // [NS] Gauss weights, [NS] mu (LDS copies for the ground-reflection sums)
+    constexpr int LPB = COLS;              // level capacity of the field storage
+    double *cbuf = smem;                   // [COLS][FS]  LDS: the field itself
+    double *gnd = cbuf + COLS * FS;        // down-going field at the ground, order ig-1: [3][NS] by (component, direction), or --
+                                           // SURF -- [KHM] in half-system order, the B operand of ground_mfma (3 NS + 2 >= KHM)
+    double *red = gnd + 3 * NS + 2;        // [16]
+    double *i3s = red + 16;                // [2][NS] I3 of the I rows (flux integrals)
+    double *lga = i3s + 2 * NS;            // [NS] Gauss weights, [NS] mu (LDS copies for the ground-reflection sums)
     double *lmu = lga + NS;
-    double *sbase = BIG ? bn.scratch + (size_t)blockIdx.x * bn.scr_stride : lmu + NS;
-    double *fld = BIG ? sbase : cbuf;      // [LPB][FS]   field / source, [level][+mu rows | -mu rows]
-    double *att = BIG ? sbase + (size_t)LPB * FS : sbase;   // [LPB][NS] exp(-dtau_i/mu_j), layer i = levels i..i+1
+    double *bcv = i3s;                     // SURF: [KHM] reflected field of ground_mfma, over i3s | lga | lmu (4 NS >= KHM), which
+                                           // the SURF variants do not use while a Fourier order runs
+    double *sbase = lmu + NS;
+    double *fld = cbuf;                    // [LPB][FS]   field / source, [level][+mu rows | -mu rows]
+    double *att = sbase;                   // [LPB][NS] exp(-dtau_i/mu_j), layer i = levels i..i+1
     double *idtau = att + (size_t)LPB * NS;  // [LPB] each:
     double *xdel = idtau + LPB;
     double *ydel = xdel + LPB;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
         double *recb = bn.rec + (size_t)b * S1 * 3 * W;
 
         __syncthreads();
-        if (t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
+        if (!SURF && t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
+        if (SURF) for (int i = t; i < 3 * NS + 2; i += NTH) gnd[i] = 0.;
         for (size_t i = t; i < (size_t)LPB * FS; i += NTH) fld[i] = 0.;
-        if (BIG) for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
         double *hh = fyd, *dtau = fxd;         // set-up only: these two slots end up holding the Fresnel factors
         for (int i = t; i < LPB; i += NTH) {
             const bool in = i <= nt;
@@ -171,11 +171,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             constexpr bool O1 = decltype(o1_tag)::value;
             if (up) {
                 if (active) scan_dir(std::integral_constant<int, -1>(), o1_tag, bcv);
-            } else if (O1 || !BIG) {          // BIG, ig >= 2: the down sweep ran chunk by chunk inside the contraction loop
-                if (active) {
-                    scan_dir(std::integral_constant<int, 1>(), o1_tag, 0.);
-                    gnd[c * NS + jj] = xb * usign;
-                }
+            } else if (active) {
+                scan_dir(std::integral_constant<int, 1>(), o1_tag, 0.);
+                gnd[SURF ? kk : c * NS + jj] = xb * usign;
             }
             if (ZO && jout && active) { xlo = fld[(size_t)jlo * FS + rl]; xhi = fld[(size_t)jhi * FS + rl]; }
         };
@@ -190,54 +188,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
         PH_T0();
         for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
             sign = -sign;
-            const float *rs = SURF ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
-            // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239)
+            // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239); every thread of the
+            // workgroup calls it (the SURF form is a workgroup-wide matrix-core product with one barrier)
+            const double *gop = SURF ? cx.mp_gnd + (size_t)s * cx.rtph * cx.ks2h * 128 : nullptr;
+            const int gstep = (jj < cx.nwgt || !SURF) ? cx.nwgt : N - cx.nwgt;    // distance of (b, jj) from (c, jj) in gnd (SURF)
             auto ground_bc = [&]() -> double {
-                if (!(active && up)) return 0.;
-                double v = 0., xr = 0.;
-                if (c == 0 && cx.ro != 0. && s == 0) {
-                    double lsol = 0.;
-#pragma unroll 1
-                    for (int j = 0; j < N; j++) lsol = lsol + lga[j] * gnd[j] * lmu[j];
-                    lsol = 2 * lsol * cx.ro;
-                    v = lsol; xr = lsol;
-                }
+                double v = 0.;
                 if (SURF) {
-                    // 3 x 3 block product with the REAL*4 matrices (SOS_OS.F:1194-1220); rs is transposed, so the lanes of a
-                    // wave (rows k) read consecutive floats and the j loop can run several loads ahead
-                    double acc2 = 0.;
-                    const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + jj;
-                    const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + jj;
-                    const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + jj;
-                    const bool pol = cx.ipolar != 0;
-                    constexpr int SB = 24;          // N = 41: two batches
+                    // BRDF/BPDF matrices (SOS_OS.F:1194-1220) and the Lambertian part, folded into G_0: see ground_mfma
+                    if (tile_b) ground_mfma<RTWH, NW>(gop, cx.ks2h, gnd, bcv, lane, wv);
+                    else if (tile_a) ground_mfma<1, NW>(gop, cx.ks2h, gnd, bcv, lane, wv);
+                    __syncthreads();
+                    if (!(active && up)) return 0.;
+                    v = bcv[kk];
+                } else {
+                    if (!(active && up)) return 0.;
+                    if (c == 0 && cx.ro != 0. && s == 0) {
+                        double lsol = 0.;
 #pragma unroll 1
-                    for (int j0 = 0; j0 < N; j0 += SB) {
-                        // 3 SB independent loads in flight per batch of SB incident directions (the matrices sit in L2: one
-                        // round trip per batch instead of one per direction)
-                        float f0[SB], f1[SB], f2[SB];
-#pragma unroll
-                        for (int u = 0; u < SB; ++u) {
-                            const size_t o = (size_t)min(j0 + u, N - 1) * N;
-                            f0[u] = r0[o]; f1[u] = r1[o]; f2[u] = r2[o];
-                        }
-#pragma unroll
-                        for (int u = 0; u < SB; ++u) {
-                            const int j = j0 + u;
-                            if (j < N) {
-                                double q0 = f0[u], q1 = f1[u], q2 = f2[u];
-                                if (!pol) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }    // SOS_OS.F:928-941
-                                acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[NS + j] * q1 + gnd[2 * NS + j] * q2);
-                            }
-                        }
+                        for (int j = 0; j < N; j++) lsol = lsol + lga[j] * gnd[j] * lmu[j];
+                        v = 2 * lsol * cx.ro;
                     }
-                    v = acc2 * (2 / mu) + xr;
                 }
                 if (cx.ifresnel == 1) {
                     const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
-                    if (c == 0) v = v + f11 * gnd[jj] + f12 * gnd[NS + jj];
-                    else if (c == 1) v = v + f12 * gnd[jj] + f11 * gnd[NS + jj];
-                    else v = v + f33 * gnd[2 * NS + jj];
+                    const double *g0 = SURF ? gnd + kk - c * gstep : gnd + jj;      // (I, jj); Q and U follow at gs, 2 gs
+                    const int gs = SURF ? gstep : NS;
+                    if (c == 0) v = v + f11 * g0[0] + f12 * g0[gs];
+                    else if (c == 1) v = v + f12 * g0[0] + f11 * g0[gs];
+                    else v = v + f33 * g0[2 * gs];
                 }
                 return v;
             };
@@ -256,12 +235,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 double v = 0.;
                 xr = 0.;
                 if (c == 0 && cx.ro != 0. && s == 0) { v = cx.ro * cx.mus * e_sun; xr = v; }
-                if (SURF) {
-                    const double rr = e_sun / mu;
-                    double r = rs[(size_t)(c * 3) * N * N + (size_t)(cx.n0 - 1) * N + jj];
-                    if (!cx.ipolar && c) r = 0.;
-                    v = v + r * rr;
-                }
+                if (SURF) v = v + cx.rdir[((size_t)s * 3 + c) * N + jj] * (e_sun / mu);      // polarisation cut applied at packing
                 return v;
             };
             double bc = 0., dirterm = 0.;          // dirterm is only kept (SURF variants) for the end of the order
@@ -271,7 +245,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
             // ---- scattering orders: formal solution of the current source, stop tests, next source ----------
             double i3 = 0., a1 = 0., d1 = 0., g1 = 0.;
             double i3lo = 0., dlo = 0., i3hi = 0., dhi = 0.;
-            double dn_z = 0., dn_s = 0.;           // BIG: running state of the chunk-wise down sweep
             int ig = 1, iglast = 1;
             for (;;) {
                 if (ig == 1) scan_row(std::true_type(), bc);                         // SOS_OS.F:1025
@@ -315,10 +288,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 if (ig > cx.igmax) break;
                 iglast = ig;
                 // source function of order ig: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
-                const int nchunk = BIG ? (nt + COLS) / COLS : 1;
-#pragma unroll 1
-                for (int chk = 0; chk < nchunk; chk++) {
-                    const int l0 = chk * COLS;                 // first level of this chunk
+                {
                     v4d acc[2][RTWH][CT];
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++)
@@ -326,10 +296,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                         for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
                             for (int ct = 0; ct < CT; ct++) acc[sy][rt][ct] = (v4d){0., 0., 0., 0.};
-                    // BIG: the B operands of this chunk are read straight from the scratch field (16 B per lane, 64 B
-                    // contiguous per column and k-pair; the four waves read the same lines, served by the CU's L1): no
-                    // staging copy and no barrier in front of the contraction.  Levels above nt are zero in the scratch.
-                    const double *bxc = BIG ? fld + (size_t)(l0 + (lane & 15)) * FS + 2 * (lane >> 4) : bx;
                     const double *mpa = cx.mp_aer + (size_t)s * mper;
                     const double *vtp = cx.mp_vt + (size_t)(s <= 2 ? s : 0) * cx.ks2h * 128;
                     const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
@@ -338,8 +304,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     auto contract = [&](auto na_tag) {
                         constexpr int NA = decltype(na_tag)::value;
 #define SOS_GEMM(RAYV, FOLDV)                                                                                          \
-    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bxc,       \
-                                                        xdel + l0, ydel + l0, lane, wv, cx.prow, pcb)
+    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,        \
+                                                        xdel, ydel, lane, wv, cx.prow, pcb)
                         if (s > 2) SOS_GEMM(-1, false);
                         else if (s & 1) { if (fold) SOS_GEMM(1, true); else SOS_GEMM(1, false); }
                         else { if (fold) SOS_GEMM(0, true); else SOS_GEMM(0, false); }
@@ -348,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                     if (tile_b) contract(std::integral_constant<int, RTWH>());
                     else if (tile_a) contract(std::integral_constant<int, 1>());
                     else if (fold) __syncthreads();                            // the barrier of the folded projection
-                    __syncthreads();             // non-BIG: every wave has read the field; BIG: previous chunk copied out
+                    __syncthreads();             // every wave has read the field
                     PH(2);
                     // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
                     // accumulators are exact zeros (zero operator rows, zero field columns) and are stored as such.
@@ -372,49 +338,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                         }
                     }
                     __syncthreads();
-                    if (BIG) {
-                        // Source chunk (levels l0..lv1) leaves LDS.  Up-going rows: S+ is copied to the scratch field (their
-                        // sweep runs from the ground upwards, after the last chunk).  Down-going rows: the chunks arrive in
-                        // the order of their sweep, so it runs here, straight from LDS -- S- never makes the round trip
-                        // through the scratch (a quarter of this variant's memory traffic).
-                        const int lv1 = min(l0 + COLS - 1, nt);
-                        if (active && up) {
-                            const double *qs = cbuf + rl;
-                            double *q = fld + (size_t)l0 * FS + rl;
-                            int lev = l0;
-#pragma unroll 1
-                            for (; lev + 8 <= lv1 + 1; lev += 8) {
-                                double v[8];
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) v[u] = qs[u * FS];
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) q[u * FS] = v[u];
-                                qs += 8 * FS; q += 8 * FS;
-                            }
-#pragma unroll 1
-                            for (; lev <= lv1; ++lev) { *q = *qs; qs += FS; q += FS; }
-                        } else if (active) {
-                            int start = l0;
-                            if (chk == 0) {                   // the ray enters at the top: X-(0) = 0, S-(0) is the first "previous" source
-                                dn_z = 0.; dn_s = cbuf[rl];
-                                fld[rl] = 0.;
-                                start = 1;
-                            }
-                            const double *qs = cbuf + (size_t)(start - l0) * FS + rl;
-                            double *q = fld + (size_t)start * FS + rl;
-                            const double *qa = att + (size_t)(start - 1) * NS + jj;
-                            const double *qd = idtau + (start - 1);
-                            int cnt = lv1 - start + 1;
-#pragma unroll 1
-                            for (; cnt >= 8; cnt -= 8) scan_block_split<8, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
-                            if (cnt & 4) scan_block_split<4, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
-                            if (cnt & 2) scan_block_split<2, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
-                            if (cnt & 1) scan_block_split<1, FS, NS>(q, qs, qa, qd, mu, dn_z, dn_s);
-                            if (lv1 == nt) { xb = dn_z; gnd[c * NS + jj] = xb * usign; }
-                        }
-                    }
                 }
-                if (BIG) __syncthreads();
                 PH(3);
             }
             // SOS_OS.F:1421-1439.  The record is built from I3OUT (minus RIIOUT at the output level), the stop
@@ -436,9 +360,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
                 __syncthreads();
                 if (t == 0) {
                     double em = 0., ep = 0.;
-                    for (int j = 0; j < N; j++) {
-                        em = em + lmu[j] * lga[j] * i3s[NS + j];
-                        ep = ep + lmu[j] * lga[j] * i3s[j];
+                    for (int j = 0; j < N; j++) {          // (mu, weights from global: the SURF variants keep no LDS copy)
+                        em = em + cx.mu[j] * cx.ga[j] * i3s[NS + j];
+                        ep = ep + cx.mu[j] * cx.ga[j] * i3s[j];
                     }
                     bn.flux[2 * b] = em * 2 / cx.mus;
                     bn.flux[2 * b + 1] = ep * 2 / cx.mus;
@@ -479,7 +403,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const Sos
 static size_t lds_bytes_for(int nw, int rtw, int ct, bool big)
 {
     const int cols = 16 * ct, fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw);
-    size_t dbl = (size_t)cols * fs + 3 * ns + 2 * ns + 16 + 2 * ns;
+    size_t dbl = (size_t)cols * fs + 3 * ns + 2 + 2 * ns + 16 + 2 * ns;
     if (!big) dbl += (size_t)cols * ns + 7 * cols;
     return dbl * sizeof(double);
 }
@@ -516,17 +440,10 @@ int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_by
     return 0;
 }
 
-size_t sos_os_scratch_doubles(int n, int lpb)
-{
-    int w, r, c, b;
-    sos_os_shape(n, 1023, &w, &r, &c, &b);            // the field-in-HBM shape of this N
-    return (size_t)lpb * (sos_fs(w, r) + sos_ns(w, r) + 7);
-}
-
-template <int NW, int RTWH, int CT, bool BIG, bool ZO, bool SURF>
+template <int NW, int RTWH, int CT, bool ZO, bool SURF>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st, int *hip_err)
 {
-    auto kern = k_sos_os<NW, RTWH, CT, BIG, ZO, SURF>;
+    auto kern = k_sos_os<NW, RTWH, CT, ZO, SURF>;
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif
@@ -546,19 +463,18 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     const int rc = sos_os_variant(cx.n, nt_max, &nw, &rtw, &ct, &lds, &big);
     if (rc) return rc;
     if (cx.kh > sos_khm(nw, rtw) || cx.rtph * 16 < cx.kh) return SOSGPU_E_UNSUPPORTED;
-    if (big && (!bn.scratch || bn.lpb < nt_max + 1)) return SOSGPU_E_UNSUPPORTED;
+    if (big) return SOSGPU_E_UNSUPPORTED;                  // streamed variant: launch_sos_stream (sos_stream.hip)
     const int zo = bn.jout != nullptr;
-#define V(NWV, R, C, B)                                                                   \
-    if (nw == NWV && rtw == R && ct == C && big == B) {                                   \
-        if (cx.imat_surf)                                                                 \
-            return zo ? launch_variant<NWV, R, C, B, true, true>(cx, bn, lds, st, hip_err)         \
-                      : launch_variant<NWV, R, C, B, false, true>(cx, bn, lds, st, hip_err);       \
-        return zo ? launch_variant<NWV, R, C, B, true, false>(cx, bn, lds, st, hip_err)            \
-                  : launch_variant<NWV, R, C, B, false, false>(cx, bn, lds, st, hip_err);          \
+#define V(NWV, R, C)                                                                   \
+    if (nw == NWV && rtw == R && ct == C) {                                            \
+        if (cx.imat_surf)                                                              \
+            return zo ? launch_variant<NWV, R, C, true, true>(cx, bn, lds, st, hip_err)         \
+                      : launch_variant<NWV, R, C, false, true>(cx, bn, lds, st, hip_err);       \
+        return zo ? launch_variant<NWV, R, C, true, false>(cx, bn, lds, st, hip_err)            \
+                  : launch_variant<NWV, R, C, false, false>(cx, bn, lds, st, hip_err);          \
     }
-    V(4, 1, 2, 0) V(4, 2, 2, 0) V(8, 2, 2, 0)
-    V(4, 1, 4, 0) V(8, 1, 4, 0)
-    V(4, 1, 2, 1) V(4, 2, 2, 1) V(8, 2, 2, 1)
+    V(4, 1, 2) V(4, 2, 2) V(8, 2, 2)
+    V(4, 1, 4) V(8, 1, 4)
 #undef V
     return SOSGPU_E_UNSUPPORTED;
 }

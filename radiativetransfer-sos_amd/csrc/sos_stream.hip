@@ -74,11 +74,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
     const int LPB = bn.lpb, NCH = LPB / COLS, VS = LPB + VPAD;
     double *cbuf = smem;                   // [COLS][FS]  the chunk: field of order ig-1, then source, then field of order ig
-    double *gnd = cbuf + COLS * FS;        // [3][NS] down-going field at the ground, order ig-1
-    double *i3s = gnd + 3 * NS;            // [2][NS] I3 of the I rows (flux integrals)
-    double *red = i3s + 2 * NS;            // [16]
-    double *lga = red + 16;                // [NS] Gauss weights, [NS] mu
+    double *gnd = cbuf + COLS * FS;        // down-going field at the ground, order ig-1: [3][NS], or -- SURF -- [KHM] in
+                                           // half-system order (B operand of ground_mfma), as in sos_os.hip
+    double *red = gnd + 3 * NS + 2;        // [16]
+    double *i3s = red + 16;                // [2][NS] I3 of the I rows (flux integrals)
+    double *lga = i3s + 2 * NS;            // [NS] Gauss weights, [NS] mu
     double *lmu = lga + NS;
+    double *bcv = i3s;                     // SURF: [KHM] result of ground_mfma, over i3s | lga | lmu
     double *catt = lmu + NS;               // [COLS][NS] 1 - exp(-dtau/mu): row r = layer l0 - 1 + r
     double *cvec = catt + COLS * NS;       // [7][VL] level vectors of the chunk
     double *cidt = cvec, *cxdel = cvec + VL, *cydel = cvec + 2 * VL, *ccxd = cvec + 3 * VL;
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
 
     // ---- per-bin set-up: level vectors, attenuation table, chunk link factors -> scratch -------------------------------
     __syncthreads();
-    if (t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
+    if (!SURF && t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
+    if (SURF) for (int i = t; i < 3 * NS + 2; i += NTH) gnd[i] = 0.;
     for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
     double *v_idt = vec, *v_xd = vec + VS, *v_yd = vec + 2 * VS, *v_cxd = vec + 3 * VS, *v_cyd = vec + 4 * VS,
            *v_fxd = vec + 5 * VS, *v_fyd = vec + 6 * VS;
@@ -194,50 +197,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     int nord = 0;
     for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
         sign = -sign;
-        const float *rs = SURF ? cx.rsurf + (size_t)s * 9 * N * N : nullptr;
-        // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239)
+        // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239); called by every thread
+        const double *gop = SURF ? cx.mp_gnd + (size_t)s * cx.rtph * cx.ks2h * 128 : nullptr;
+        const int gstep = (jj < cx.nwgt || !SURF) ? cx.nwgt : N - cx.nwgt;
         auto ground_bc = [&]() -> double {
-            if (!(active && up)) return 0.;
-            double v = 0., xr = 0.;
-            if (c == 0 && cx.ro != 0. && s == 0) {
-                double lsol = 0.;
-#pragma unroll 1
-                for (int j = 0; j < N; j++) lsol = lsol + lga[j] * gnd[j] * lmu[j];
-                lsol = 2 * lsol * cx.ro;
-                v = lsol; xr = lsol;
-            }
+            double v = 0.;
             if (SURF) {
-                double acc2 = 0.;
-                const float *r0 = rs + (size_t)(c * 3 + 0) * N * N + jj;
-                const float *r1 = rs + (size_t)(c * 3 + 1) * N * N + jj;
-                const float *r2 = rs + (size_t)(c * 3 + 2) * N * N + jj;
-                const bool pol = cx.ipolar != 0;
-                constexpr int SB = 24;
+                if (tile_b) ground_mfma<RTWH, NW>(gop, cx.ks2h, gnd, bcv, lane, wv);
+                else if (tile_a) ground_mfma<1, NW>(gop, cx.ks2h, gnd, bcv, lane, wv);
+                __syncthreads();
+                if (!(active && up)) return 0.;
+                v = bcv[kk];
+            } else {
+                if (!(active && up)) return 0.;
+                if (c == 0 && cx.ro != 0. && s == 0) {
+                    double lsol = 0.;
 #pragma unroll 1
-                for (int j0 = 0; j0 < N; j0 += SB) {
-                    float f0[SB], f1[SB], f2[SB];
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const size_t o = (size_t)min(j0 + u, N - 1) * N;
-                        f0[u] = r0[o]; f1[u] = r1[o]; f2[u] = r2[o];
-                    }
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const int j = j0 + u;
-                        if (j < N) {
-                            double q0 = f0[u], q1 = f1[u], q2 = f2[u];
-                            if (!pol) { q1 = 0.; q2 = 0.; if (c) q0 = 0.; }    // SOS_OS.F:928-941
-                            acc2 = acc2 + lga[j] * (gnd[j] * q0 + gnd[NS + j] * q1 + gnd[2 * NS + j] * q2);
-                        }
-                    }
+                    for (int j = 0; j < N; j++) lsol = lsol + lga[j] * gnd[j] * lmu[j];
+                    v = 2 * lsol * cx.ro;
                 }
-                v = acc2 * (2 / mu) + xr;
             }
             if (cx.ifresnel == 1) {
                 const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
-                if (c == 0) v = v + f11 * gnd[jj] + f12 * gnd[NS + jj];
-                else if (c == 1) v = v + f12 * gnd[jj] + f11 * gnd[NS + jj];
-                else v = v + f33 * gnd[2 * NS + jj];
+                const double *g0 = SURF ? gnd + kk - c * gstep : gnd + jj;
+                const int gs = SURF ? gstep : NS;
+                if (c == 0) v = v + f11 * g0[0] + f12 * g0[gs];
+                else if (c == 1) v = v + f12 * g0[0] + f11 * g0[gs];
+                else v = v + f33 * g0[2 * gs];
             }
             return v;
         };
@@ -253,10 +239,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
             double xr = 0.;
             if (c == 0 && cx.ro != 0. && s == 0) { bc = cx.ro * cx.mus * e_sun; xr = bc; }
             if (SURF) {
-                const double rr = e_sun / mu;
-                double r = rs[(size_t)(c * 3) * N * N + (size_t)(cx.n0 - 1) * N + jj];
-                if (!cx.ipolar && c) r = 0.;
-                bc = bc + r * rr;
+                bc = bc + cx.rdir[((size_t)s * 3 + c) * N + jj] * (e_sun / mu);
                 dirterm = bc - xr;                                                       // SOS_OS.F:1070-1072
             }
         }
@@ -357,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                     if (cnt & 4) scan_block<1, 4, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
                     if (cnt & 2) scan_block<1, 2, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
                     if (cnt & 1) scan_block<1, 1, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
-                    if (L == nt) { xb = dn_z; gnd[c * NS + jj] = xb * usign; }
+                    if (L == nt) { xb = dn_z; gnd[SURF ? kk : c * NS + jj] = xb * usign; }
                     if (ZO && jout) {
                         if (jlo >= l0 && jlo <= L) xlo = cbuf[(size_t)(jlo - l0) * FS + rl];
                         if (jhi >= l0 && jhi <= L) xhi = cbuf[(size_t)(jhi - l0) * FS + rl];
@@ -495,8 +478,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
             if (t == 0) {
                 double em = 0., ep = 0.;
                 for (int j = 0; j < N; j++) {
-                    em = em + lmu[j] * lga[j] * i3s[NS + j];
-                    ep = ep + lmu[j] * lga[j] * i3s[j];
+                    em = em + cx.mu[j] * cx.ga[j] * i3s[NS + j];
+                    ep = ep + cx.mu[j] * cx.ga[j] * i3s[j];
                 }
                 bn.flux[2 * b] = em * 2 / cx.mus;
                 bn.flux[2 * b + 1] = ep * 2 / cx.mus;
@@ -528,7 +511,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
 static size_t stream_lds_bytes(int nw, int rtw)
 {
     const int fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw);
-    return ((size_t)COLS * fs + 3 * ns + 2 * ns + 16 + 2 * ns + (size_t)COLS * ns + 7 * (COLS + VPAD)) * sizeof(double);
+    return ((size_t)COLS * fs + 3 * ns + 2 + 2 * ns + 16 + 2 * ns + (size_t)COLS * ns + 7 * (COLS + VPAD)) * sizeof(double);
 }
 
 static void stream_shape(int n, int *nw, int *rtw)
