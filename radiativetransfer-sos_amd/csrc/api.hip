@@ -235,7 +235,8 @@ __global__ void k_pack_ground(SosDev cx, const float *__restrict__ r, double *__
     if (q < per) {
         const int e2 = q & 1, lane = (q >> 1) & 63;
         const int m = (int)((q >> 7) % cx.ks2h), rt = (int)((q >> 7) / cx.ks2h);
-        const int row = rt * 16 + (lane & 15), col = 8 * m + 2 * (lane >> 4) + e2;
+        // A-operand order of v_mfma_f64_4x4x4f64 (sos_dev.h ground_mfma): block = row quad, lane>>4 = k
+        const int row = rt * 16 + ((lane >> 2) & 3) * 4 + (lane & 3), col = 8 * m + 4 * e2 + (lane >> 4);
         double v = 0.;
         if (row < 3 * N && col < 3 * N) {
             const int ro = cx.rowmap[row], co = cx.rowmap[col];

@@ -250,45 +250,49 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 // Ground reflection of the down-going field of the previous scattering order by a BRDF/BPDF surface (SOS_OS.F:1194-1220):
 //   X_a(NT, k) = (2/mu_k) sum_j w_j sum_b X_b(NT, -j) R_ab(j, k)            (+ the Lambertian term on I for s = 0)
 // a 3N x 3N matrix-vector product per scattering order.  As per-thread dot products over REAL*4 matrices in L2 it cost as much
-// as half a source contraction (latency of 3N loads per row); here it is one more small matrix-core product against the
-// operator G_s packed like the source operators (SosDev::mp_gnd): wave w does row tiles {w, w + NW}, the B operand is the
-// ground vector gndk (half-system order, LDS) broadcast to all 16 columns, and the lanes of column 0 publish the result.
+// as half a source contraction (latency of 3N loads per row); here it is a small matrix-core product against the operator G_s
+// (SosDev::mp_gnd) on v_mfma_f64_4x4x4f64 -- four independent 4 x 4 x 4 blocks per instruction, 16 cycles: the four blocks
+// are four row quads of one 16-row tile, the vector is broadcast to the four columns, so an instruction does 64 useful
+// multiply-adds in a quarter of the time the 16 x 16 x 4 form needs for the same 64.  Operand layout (probed on gfx950,
+// scripts/probe_mfma4x4.hip): A[blk][i][k] in lane i + 4 blk + 16 k, B[blk][k][j] in lane j + 4 blk + 16 k,
+// D[blk][i][j] in lane j + 4 blk + 16 i.  Packed operator (api.hip k_pack_ground):
+//   gp[((tile * KS2H + m) * 64 + lane) * 2 + e] = G[tile*16 + 4 ((lane>>2)&3) + (lane&3)][8 m + 4 e + (lane>>4)]
+// Wave w does row tiles {w, w + NW}; gndk = ground vector in half-system order (LDS); the lanes of column 0 publish bcv.
 template <int NA, int NW>
 __device__ __forceinline__ void ground_mfma(const double *__restrict__ gp, int ks2h, const double *gndk, double *bcv, int lane,
                                             int tile0)
 {
-    v4d acc[NA];
+    double acc[NA];
 #pragma unroll
-    for (int rt = 0; rt < NA; rt++) acc[rt] = (v4d){0., 0., 0., 0.};
+    for (int rt = 0; rt < NA; rt++) acc[rt] = 0.;
     const size_t rts = (size_t)ks2h * 64;
     const v2d *ap = reinterpret_cast<const v2d *>(gp) + (size_t)tile0 * rts + lane;
-    const v2d *bp = reinterpret_cast<const v2d *>(gndk) + (lane >> 4);      // K indices 8m + 2q + {0,1} -> v2d 4m + q
-    constexpr int MB = 8;                     // k-pairs requested together: one L2 round trip per batch (N = 41: two batches)
+    const double *bp = gndk + (lane >> 4);
+    constexpr int MB = 5;                     // k-pairs requested together
 #pragma unroll 1
     for (int m = 0; m < ks2h; m += MB) {
-        v2d a[MB][NA], b[MB];
+        v2d a[MB][NA];
+        double b0[MB], b1[MB];
 #pragma unroll
         for (int u = 0; u < MB; u++) {
             const int mm = min(m + u, ks2h - 1);
 #pragma unroll
             for (int rt = 0; rt < NA; rt++) a[u][rt] = ap[(size_t)rt * NW * rts + (size_t)mm * 64];
-            b[u] = bp[4 * mm];
+            b0[u] = bp[8 * mm]; b1[u] = bp[8 * mm + 4];
         }
 #pragma unroll
         for (int u = 0; u < MB; u++)
             if (m + u < ks2h) {                                               // wave-uniform
 #pragma unroll
                 for (int rt = 0; rt < NA; rt++) {
-                    acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][rt].x, b[u].x, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][rt].y, b[u].y, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][rt].x, b0[u], acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][rt].y, b1[u], acc[rt], 0, 0, 0);
                 }
             }
     }
-    if ((lane & 15) == 0) {
+    if ((lane & 3) == 0) {
 #pragma unroll
-        for (int rt = 0; rt < NA; rt++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) bcv[(tile0 + rt * NW) * 16 + 4 * e + (lane >> 4)] = acc[rt][e];
+        for (int rt = 0; rt < NA; rt++) bcv[(tile0 + rt * NW) * 16 + ((lane >> 2) & 3) * 4 + (lane >> 4)] = acc[rt];
     }
 }
 
