@@ -165,9 +165,26 @@ int  sosgpu_mat_fresnel_host(int n, const double *mu, const double *chr, double 
  *               when the context has ifresnel = 1
  *  d_out[nphi][7][W]: XIT, XQT, XUT, ANGDIFF (deg), polarisation angle, rate (%), polarised radiance;
  *               slot jj = 0 is zero.
- * Land BRDF/BPDF direct terms (IROUJEAN, IRONDEAUX, IBREON, INADAL, IMAIGNAN) are not implemented. */
+ *  land         NULL, or the land-surface model of -SURF.Type 3..7 whose directly reflected term is added
+ *               (SOS_TRPHI.F:1047-1200): Roujean BRDF for every type, plus the BPDF of type 4..7. */
+typedef struct sosgpu_land {
+    int32_t isurf;            /* 3 Roujean, 4 + Rondeaux-Herman, 5 + Breon, 7 + Maignan (SOS_PREPA_OS.F:479-497); 6 (Nadal) is
+                               * refused with SOSGPU_E_UNSUPPORTED, as the reference's SOS_PROC refuses it */
+    int32_t reserved;
+    double  k0, k1, k2;       /* Roujean coefficients */
+    double  alpha, beta;      /* Nadal (kept for layout compatibility, unused) */
+    double  coef_c;           /* Maignan C exp(-NDVI) */
+} sosgpu_land;
 int  sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
-                  const double *d_phi, int igli, double wind, double *d_out, void *stream);
+                  const double *d_phi, int igli, double wind, const sosgpu_land *land, double *d_out, void *stream);
+
+/* Replaces SOS_ROUJEAN (src/SOS_ROUJEAN.F:212), SOS_SURFACE_BPDF (src/SOS_SURFACE_BPDF.F:219) and SOS_BPDF_AJOUT_BRDF
+ * (src/SOS_SURFACE.F:2503) for -SURF.Type 3..7, no temporary files: Fourier reflection matrices of the land surface,
+ *  d_rsurf[os_nb+1][9][N][N]  REAL*4, reference surface-file record order (feed to sosgpu_set_surface_matrices).
+ * Host inputs mu[n], chr[n]; ind = surface refractive index (BPDF types).  *ier_out (host) = 0, or -1 when the Roujean BRDF
+ * goes negative for some geometry (the reference's IER = -1, SOS_ROUJEAN.F:548).  Synchronous. */
+int  sosgpu_land_surface(int device, const sosgpu_land *land, int n, const double *mu, const double *chr, double ind,
+                         int os_nb, int os_ns, int os_nm, float *d_rsurf, int32_t *ier_out, void *stream);
 
 /* Scratch requirements (bytes) of the context on its device, for memory planning. */
 size_t sosgpu_ctx_bytes(const sosgpu_ctx *cx);

@@ -17,7 +17,7 @@ EXPORTS = [
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
     "sosgpu_debug_phase_buffer", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
-    "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce", "sosgpu_absprofile",
+    "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce", "sosgpu_absprofile", "sosgpu_land_surface",
 ]
 SCAL_BASE = 10          # SOSGPU_SCAL_BASE: scalar block of sosgpu_aggregate = SCAL_BASE + N doubles
 
@@ -35,6 +35,12 @@ class Wave(C.Structure):
     _fields_ = [("n", C.c_int32), ("os_nb", C.c_int32), ("n0", C.c_int32), ("imat_surf", C.c_int32),
                 ("ifresnel", C.c_int32), ("ipolar", C.c_int32), ("igmax", C.c_int32), ("reserved", C.c_int32),
                 ("ro", C.c_double), ("ind_surf", C.c_double), ("ron", C.c_double)]
+
+
+class Land(C.Structure):
+    """struct sosgpu_land"""
+    _fields_ = [("isurf", C.c_int32), ("reserved", C.c_int32), ("k0", C.c_double), ("k1", C.c_double), ("k2", C.c_double),
+                ("alpha", C.c_double), ("beta", C.c_double), ("coef_c", C.c_double)]
 
 
 _lib = None
@@ -96,7 +102,9 @@ def lib():
         L.sosgpu_mat_fresnel_host.restype = i32
         L.sosgpu_mat_fresnel_host.argtypes = [i32, vp, vp, dbl, i32, vp]
         L.sosgpu_trphi.restype = i32
-        L.sosgpu_trphi.argtypes = [vp, i32, vp, dbl, dbl, i32, vp, i32, dbl, vp, vp]
+        L.sosgpu_trphi.argtypes = [vp, i32, vp, dbl, dbl, i32, vp, i32, dbl, C.POINTER(Land), vp, vp]
+        L.sosgpu_land_surface.restype = i32
+        L.sosgpu_land_surface.argtypes = [i32, C.POINTER(Land), i32, vp, vp, dbl, i32, i32, i32, vp, C.POINTER(C.c_int32), vp]
         L.sosgpu_debug_phase_buffer.restype = i32
         L.sosgpu_debug_phase_buffer.argtypes = [vp, vp]
         _lib = L

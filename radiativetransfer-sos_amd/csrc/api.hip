@@ -666,13 +666,70 @@ extern "C" int sosgpu_glitter(int device, int n, const double *mu, const double 
     return SOSGPU_OK;
 }
 
+static LandTerms land_terms(const sosgpu_land *land)
+{
+    LandTerms t;
+    memset(&t, 0, sizeof t);
+    if (land && land->isurf >= 3) {
+        t.iroujean = 1;
+        t.irondeaux = land->isurf == 4; t.ibreon = land->isurf == 5; t.imaignan = land->isurf == 7;
+        t.k0 = land->k0; t.k1 = land->k1; t.k2 = land->k2; t.coef_c = land->coef_c;
+    }
+    return t;
+}
+
 extern "C" int sosgpu_trphi(sosgpu_ctx *cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
-                            const double *d_phi, int igli, double wind, double *d_out, void *stream)
+                            const double *d_phi, int igli, double wind, const sosgpu_land *land, double *d_out, void *stream)
 {
     if (!cx || nf < 1 || nf > cx->d.smax + 1 || !d_rec || nphi < 1 || !d_phi || !d_out) return SOSGPU_E_ARG;
+    if (land && (land->isurf < 3 || land->isurf > 7)) return SOSGPU_E_ARG;
+    if (land && land->isurf == 6) return SOSGPU_E_UNSUPPORTED;       // Nadal: refused by the reference's SOS_PROC as well
     HIPCHK(hipSetDevice(cx->device));
-    launch_trphi(cx->d, nf, d_rec, tau, tauout, nphi, d_phi, igli, sigma2_of_wind(wind), cx->ind_surf, d_out, (hipStream_t)stream);
+    launch_trphi(cx->d, nf, d_rec, tau, tauout, nphi, d_phi, igli, sigma2_of_wind(wind), cx->ind_surf, land_terms(land), d_out,
+                 (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_land_surface(int device, const sosgpu_land *land, int n, const double *mu, const double *chr, double ind,
+                                   int os_nb, int os_ns, int os_nm, float *d_rsurf, int32_t *ier_out, void *stream)
+{
+    if (!land || land->isurf < 3 || land->isurf > 7 || n < 1 || n > 85 || !mu || !chr || !d_rsurf) return SOSGPU_E_ARG;
+    if (land->isurf == 6) return SOSGPU_E_UNSUPPORTED;               // Nadal: refused by the reference's SOS_PROC as well
+    if (os_nb < 0 || os_ns < 2 || os_nm < os_nb + os_ns || os_nm > 2000) return SOSGPU_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> fcoef((size_t)4 * (os_ns + 1), 0.);
+    if (land->isurf > 3) {
+        int rc = sosgpu_mat_fresnel_host(n, mu, chr, ind, os_ns, fcoef.data());
+        if (rc) return rc;
+    }
+    const size_t npairs = (size_t)n * (n + 1) / 2, nn = (size_t)n * n, cnt = (size_t)(os_nb + 1) * 9 * nn;
+    // one allocation: mu | fcoef | e_nn [N^2][os_nb+1] | e [npairs][os_nm+1] | il_nn, il, err (int32) | tmp matrices (float)
+    const size_t nd = (size_t)n + fcoef.size() + nn * (os_nb + 1) + npairs * (os_nm + 1);
+    const size_t ni = nn + npairs + 2;
+    char *buf = nullptr;
+    HIPCHK(hipMalloc((void **)&buf, nd * 8 + ni * 4 + cnt * 4 + 64));
+    double *d_mu = (double *)buf, *d_fc = d_mu + n, *d_enn = d_fc + fcoef.size(), *d_e = d_enn + nn * (os_nb + 1);
+    int32_t *d_ilnn = (int32_t *)(d_e + npairs * (os_nm + 1)), *d_il = d_ilnn + nn, *d_err = d_il + npairs;
+    float *d_tmp = (float *)(d_err + 2);
+    int32_t err[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(d_mu, mu, n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_fc, fcoef.data(), fcoef.size() * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 2 * sizeof(int32_t), st);
+    if (e == hipSuccess) {
+        launch_land(land->isurf, n, d_mu, land->k0, land->k1, land->k2, land->coef_c, os_nb, os_ns,
+                    os_nm, d_fc, d_enn, d_ilnn, d_e, d_il, d_tmp, d_rsurf, d_err, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(err, d_err, sizeof err, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    HIPCHK(e);
+    if (ier_out) *ier_out = err[0] ? -1 : 0;
     return SOSGPU_OK;
 }
 

@@ -26,11 +26,20 @@
 #define PH_NQ 10
 #define PH_TEST 10000
 
-__device__ __forceinline__ double calcg(double cs12, double c12, double s12, double sig, double phi)
-{   // SOS_CALCG, SOS_GLITTER.F:779-781
-    const double costetad = -c12 + s12 * cos(phi);
-    const double x = (1 - costetad) / cs12;
-    return x * x * exp(-(x - 1) / sig);
+// MODEL 0: Cox-Munk facet function, SOS_CALCG (SOS_GLITTER.F:779-781), par = sigma^2
+// MODEL 1: Maignan BPDF, SOS_CALCG_MAIGNAN (SOS_SURFACE_BPDF.F:1606-1641), par = C exp(-NDVI); cs12 then holds 1/C1 + 1/C2
+template <int MODEL>
+__device__ __forceinline__ double calcg(double cs12, double c12, double s12, double par, double phi)
+{
+    if (MODEL == 0) {
+        const double costetad = -c12 + s12 * cos(phi);
+        const double x = (1 - costetad) / cs12;
+        return x * x * exp(-(x - 1) / par);
+    }
+    const double cos2i = c12 - s12 * cos(phi);
+    double tan2i = (1 - cos2i) / (1 + cos2i);
+    if (tan2i < 0.) tan2i = 0.;
+    return par * exp(-sqrt(tan2i)) / cs12;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -40,7 +49,9 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// il[pair], e[pair][os_nm+1] (zero beyond IL); pairs ordered (I1 = 1..N, I2 = 1..I1)
+// il[pair], e[pair][os_nm+1] (zero beyond IL); pairs ordered (I1 = 1..N, I2 = 1..I1).  The same quadrature serves
+// SOS_GSF (MODEL 0) and SOS_GSF_MAIGNAN (MODEL 1, SOS_SURFACE_BPDF.F:1305-1600): only the function differs.
+template <int MODEL>
 __global__ __launch_bounds__(64) void k_gsf(const double *__restrict__ mu, double sig, int os_nm,
                                            int32_t *__restrict__ il_out, double *__restrict__ e_out)
 {
@@ -54,8 +65,9 @@ __global__ __launch_bounds__(64) void k_gsf(const double *__restrict__ mu, doubl
     const double c12 = c1 * c2, s12 = s1 * s2;
     double cs12 = (c1 + c2);
     cs12 = .5 * cs12 * cs12;
-    const double gmax = calcg(cs12, c12, s12, sig, 0.0);
-    double gmin = calcg(cs12, c12, s12, sig, pi);
+    if (MODEL == 1) cs12 = 1. / c1 + 1. / c2;
+    const double gmax = calcg<MODEL>(cs12, c12, s12, sig, 0.0);
+    double gmin = calcg<MODEL>(cs12, c12, s12, sig, pi);
     double phib, q;
     bool full = (PH_TEST * gmin >= gmax);
     if (full) {                                   // SOS_GLITTER.F:568-578
@@ -65,13 +77,13 @@ __global__ __launch_bounds__(64) void k_gsf(const double *__restrict__ mu, doubl
         double phi1 = 0, phi2 = pi;
         for (int it = 0; it < 200; it++) {
             phib = .5 * (phi1 + phi2);
-            const double x = PH_TEST * calcg(cs12, c12, s12, sig, phib);
+            const double x = PH_TEST * calcg<MODEL>(cs12, c12, s12, sig, phib);
             if (fabs(x - gmax) < (double).01f * gmax) break;
             if (x <= gmax) phi2 = phib; else phi1 = phib;
         }
         q = phib / PH_NU;
     }
-    for (int i = lane; i <= PH_NU; i += 64) u[i] = (i == 0) ? gmax : calcg(cs12, c12, s12, sig, q * i);
+    for (int i = lane; i <= PH_NU; i += 64) u[i] = (i == 0) ? gmax : calcg<MODEL>(cs12, c12, s12, sig, q * i);
     __syncthreads();
     if (!full) gmin = u[PH_NU];
     double *e = e_out + (size_t)pair * (os_nm + 1);
@@ -247,11 +259,23 @@ __global__ void k_mat_reflexion(int n, const double *__restrict__ mu, double coe
 #undef KX
 }
 
+void launch_gsf(int model, int n, const double *d_mu, double par, int os_nm, int32_t *d_il, double *d_e, hipStream_t st)
+{
+    const int npairs = n * (n + 1) / 2;
+    if (model == 0) k_gsf<0><<<npairs, 64, 0, st>>>(d_mu, par, os_nm, d_il, d_e);
+    else k_gsf<1><<<npairs, 64, 0, st>>>(d_mu, par, os_nm, d_il, d_e);
+}
+
+void launch_mat_reflexion(int n, const double *d_mu, double coef, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
+                          const int32_t *d_il, const double *d_e, float *d_rsurf, hipStream_t st)
+{
+    const size_t sh = ((size_t)(os_nm + 1) + 12 * (size_t)(os_ns + 1)) * sizeof(double);
+    k_mat_reflexion<<<n * (n + 1) / 2, 128, sh, st>>>(n, d_mu, coef, os_nb, os_ns, os_nm, d_fcoef, d_il, d_e, d_rsurf);
+}
+
 void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
                     int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st)
 {
-    const int npairs = n * (n + 1) / 2;
-    k_gsf<<<npairs, 64, 0, st>>>(d_mu, sig, os_nm, d_il, d_e);
-    const size_t sh = ((size_t)(os_nm + 1) + 12 * (size_t)(os_ns + 1)) * sizeof(double);
-    k_mat_reflexion<<<npairs, 128, sh, st>>>(n, d_mu, 1. / sig, os_nb, os_ns, os_nm, d_fcoef, d_il, d_e, d_rsurf);
+    launch_gsf(0, n, d_mu, sig, os_nm, d_il, d_e, st);
+    launch_mat_reflexion(n, d_mu, 1. / sig, os_nb, os_ns, os_nm, d_fcoef, d_il, d_e, d_rsurf, st);
 }

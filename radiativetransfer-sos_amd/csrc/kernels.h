@@ -22,8 +22,21 @@ void launch_aggregate(const SosDev &cx, int nseg, const int32_t *d_seg, const do
 
 void launch_glitter(int n, const double *d_mu, double sig, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
                     int32_t *d_il, double *d_e, float *d_rsurf, hipStream_t st);
+// pieces of the surface-matrix chains (glitter.hip / land.hip): azimuth quadrature of SOS_GSF (model 0: Cox-Munk, par = sigma^2)
+// or SOS_GSF_MAIGNAN (model 1, par = C exp(-NDVI)); SOS_MAT_REFLEXION + SOS_MISE_FORMAT with COEF = 1/sigma^2 or 1
+void launch_gsf(int model, int n, const double *d_mu, double par, int os_nm, int32_t *d_il, double *d_e, hipStream_t st);
+void launch_mat_reflexion(int n, const double *d_mu, double coef, int os_nb, int os_ns, int os_nm, const double *d_fcoef,
+                          const int32_t *d_il, const double *d_e, float *d_rsurf, hipStream_t st);
+// land surfaces (-SURF.Type 3, 4, 5, 7): Roujean BRDF, + Rondeaux-Herman / Breon / Maignan BPDF
+void launch_land(int isurf, int n, const double *d_mu, double k0, double k1, double k2, double coef_c, int os_nb, int os_ns, int os_nm, const double *d_fcoef, double *d_e_nn, int32_t *d_il_nn,
+                 double *d_e, int32_t *d_il, float *d_tmp, float *d_rsurf, int32_t *d_err, hipStream_t st);
+struct LandTerms {            // direct surface terms of the land models in SOS_TRPHI (SOS_PREPA_OS.F:479-497 flags)
+    int iroujean, irondeaux, ibreon, imaignan;
+    double k0, k1, k2, coef_c;
+};
 void launch_trphi(const SosDev &cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
-                  const double *d_phi, int igli, double sigma2, double ind_surf, double *d_out, hipStream_t st);
+                  const double *d_phi, int igli, double sigma2, double ind_surf, const LandTerms &land, double *d_out,
+                  hipStream_t st);
 
 #define SOS_PROF_NBLEV_MAX 64     // levels of the absorption profile held in LDS (CTE_ABS_NBLEV = 50 in the reference)
 // Per-bin profile discretisation (profile.hip).  *_ng: the no-gas profile of the wavelength (host-computed, device copy).

@@ -5,11 +5,13 @@
 // launch (the reference re-opens and re-reads the result file once per azimuth, SOS_TRPHI.F:558-613).
 // One workgroup per azimuth, one thread per direction jj in -N..N; the Fourier sum runs in the
 // reference's order (s ascending).  HBM-streaming bound but tiny: F*3*(2N+1)*8 bytes per azimuth, L2 hits.
-// Land BRDF/BPDF direct terms (Roujean/Rondeaux/Breon/Nadal/Maignan, :1047-1200) are not in round-1 scope.
+// The direct surface term covers the Cox-Munk glint (:946-1001), the flat-sea sun glint (:1008-1039) and the land models:
+// Roujean (:1047-1076) and Rondeaux / Breon / Maignan (:1084-1136); Nadal (:1145-1200) is refused upstream by SOS_PROC.
 #include "sos_common.h"
 #include "kernels.h"
 
 #pragma clang fp contract(off)
+#include "land_models.h"
 
 #define SEUIL_Z ((double)0.0001f)      // SOS.h:407 (REAL*4 literal)
 #define SEUIL_X ((double)0.00001f)     // SOS.h:413
@@ -32,7 +34,8 @@ __device__ inline void reflex(double cosdif, double ind, double &r11, double &r1
 
 // out[iphi][q][W], q = 0 XIT, 1 XQT, 2 XUT, 3 ANGDIFF, 4 XAN (polarisation angle), 5 TPOL, 6 LPOL
 __global__ void k_trphi(SosDev cx, int nf, const double *__restrict__ rec, double tau, double tauout,
-                        const double *__restrict__ phis, int igli, double sigma2, double ind_surf, double *__restrict__ out)
+                        const double *__restrict__ phis, int igli, double sigma2, double ind_surf, LandTerms land,
+                        double *__restrict__ out)
 {
     const int iphi = blockIdx.x;
     const int N = cx.n, W = cx.w;
@@ -57,6 +60,23 @@ __global__ void k_trphi(SosDev cx, int nf, const double *__restrict__ rec, doubl
         xut = xut + 2. * r[2 * W + t] * sn;
         xit = xit + 2. * r[0 * W + t] * cs;
     }
+    // SOS_ANGLE (:1365-1372) + SOS_REFLEX + SOS_MATRIC (:1526-1538): first column of the Fresnel reflection matrix of the
+    // facet that sends the sun (c0) into the direction c1 at azimuth phi
+    auto fresnel_column = [&](double c1, double &m11, double &m21, double &m31, double &r12_out) {
+        double s = 1.;
+        if (sin(phi) > 0.0) s = -1.;
+        const double cosdif = -c0 * c1 + sqrt(1 - c0 * c0) * sqrt(1 - c1 * c1) * cos(phi);
+        const double z = s * (sqrt(1 - cosdif * cosdif)) * (sqrt(1 - c1 * c1));
+        double coskip = 0.;
+        if (fabs(z) > SEUIL_Z) coskip = (c1 * cosdif + c0) / z;
+        double r11, r12, r33;
+        reflex(cosdif, ind_surf, r11, r12, r33);
+        const double x = 1. - fabs(coskip);
+        double c2 = 1., s2 = 0.;
+        if (x >= SEUIL_X) { c2 = 2. * coskip * coskip - 1.; s2 = 2. * coskip * sqrt(1. - coskip * coskip); }
+        if (coskip == 0.0) r12 = 0.;
+        m11 = r11; m21 = c2 * r12; m31 = s2 * r12; r12_out = r12;
+    };
     if (igli == 1 && j > 0) {                      // SOS_TRPHI.F:946-1001
         const double c1 = rmuj;
         const double at0 = exp(-tau / c0);
@@ -76,21 +96,25 @@ __global__ void k_trphi(SosDev cx, int nf, const double *__restrict__ rec, doubl
                 p = pp / (4 * c1 * (c0n2 * c0n2));
             }
         }
-        // SOS_ANGLE :1365-1372
-        double s = 1.;
-        if (sin(phi) > 0.0) s = -1.;
-        const double cosdif = -c0 * c1 + sqrt(1 - c0 * c0) * sqrt(1 - c1 * c1) * cos(phi);
-        const double z = s * (sqrt(1 - cosdif * cosdif)) * (sqrt(1 - c1 * c1));
-        double coskip = 0.;
-        if (fabs(z) > SEUIL_Z) coskip = (c1 * cosdif + c0) / z;
-        double r11, r12, r33;
-        reflex(cosdif, ind_surf, r11, r12, r33);
-        // SOS_MATRIC :1526-1538
-        const double x = 1. - fabs(coskip);
-        double c2 = 1., s2 = 0.;
-        if (x >= SEUIL_X) { c2 = 2. * coskip * coskip - 1.; s2 = 2. * coskip * sqrt(1. - coskip * coskip); }
-        if (coskip == 0.0) r12 = 0.;
-        const double m11 = r11, m21 = c2 * r12, m31 = s2 * r12;
+        double m11, m21, m31, r12;
+        fresnel_column(c1, m11, m21, m31, r12);
+        xit = xit + m11 * atj * p;
+        if (cx.ipolar == 1) { xqt = xqt + m21 * atj * p; xut = xut + m31 * atj * p; }
+    }
+    if (land.iroujean == 1 && j > 0) {             // SOS_TRPHI.F:1047-1076
+        const double c1 = rmuj;
+        const double atj = exp(-tau / c0) * exp(-(tau - tauout) / c1);
+        const double f = calc_f_roujean(land.k0, land.k1, land.k2, c0, sqrt(1. - c0 * c0), c1, sqrt(1. - c1 * c1), pi - phi);
+        xit = xit + atj * f / c1;
+    }
+    if ((land.irondeaux == 1 || land.ibreon == 1 || land.imaignan == 1) && j > 0) {   // SOS_TRPHI.F:1084-1136
+        const double c1 = rmuj;
+        const double atj = exp(-tau / c0) * exp(-(tau - tauout) / c1);
+        double m11, m21, m31, r12, p = 0.;
+        fresnel_column(c1, m11, m21, m31, r12);
+        if (land.irondeaux == 1) p = 1. / (4. * (1 + c1 / c0));
+        if (land.ibreon == 1) p = 1. / (4. * c1);
+        if (land.imaignan == 1) p = calcg_maignan(c0, c1, sqrt(1. - c0 * c0) * sqrt(1. - c1 * c1), phi, land.coef_c) / (4. * c1);
         xit = xit + m11 * atj * p;
         if (cx.ipolar == 1) { xqt = xqt + m21 * atj * p; xut = xut + m31 * atj * p; }
     }
@@ -128,7 +152,8 @@ __global__ void k_trphi(SosDev cx, int nf, const double *__restrict__ rec, doubl
 }
 
 void launch_trphi(const SosDev &cx, int nf, const double *d_rec, double tau, double tauout, int nphi,
-                  const double *d_phi, int igli, double sigma2, double ind_surf, double *d_out, hipStream_t st)
+                  const double *d_phi, int igli, double sigma2, double ind_surf, const LandTerms &land, double *d_out,
+                  hipStream_t st)
 {
-    k_trphi<<<nphi, sos_round_up(cx.w, 64), 0, st>>>(cx, nf, d_rec, tau, tauout, d_phi, igli, sigma2, ind_surf, d_out);
+    k_trphi<<<nphi, sos_round_up(cx.w, 64), 0, st>>>(cx, nf, d_rec, tau, tauout, d_phi, igli, sigma2, ind_surf, land, d_out);
 }

@@ -326,7 +326,7 @@ def profile_nogas(tr, hr, ta, ha):
     return _round_sig(h, 8), _round_sig(pcaer, 8), _round_sig(pcmol, 8), np.round(z, 5)
 
 
-def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind):
+def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, land=None):
     """SOS_TRPHI_OPTION (SOS_TRPHI.F:431-615): run the azimuth recomposition on the GPU for the azimuth list of
     the view mode and pack the fourteen (361,81) tables plus PHI_FIN(361), THETA_FIN(81)."""
     n = ctx.n
@@ -346,7 +346,7 @@ def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind):
         phi_fin[:len(iphis)] = iphis
     else:
         raise SosProcError("-SOS.View must be 1 or 2")
-    out = ctx.trphi(rec, nf, tau, tauout, phis, igli=igli, wind=wind).cpu().numpy()
+    out = ctx.trphi(rec, nf, tau, tauout, phis, igli=igli, wind=wind, land=land).cpu().numpy()
     theta_fin[:n] = teta
     names = ["i", "q", "u", "sca", "ang", "rate", "lpol"]       # order of sosgpu_trphi's 7 output rows
     for k, row in enumerate(rows):
@@ -382,8 +382,8 @@ def sos_proc(aer_phase=None, device=0, **kw):
     absprofil = int(p["absprofil"])
     if absprofil == _I or not 0 <= absprofil <= 7:
         raise SosProcError("-AP.AbsProfile.Type must be defined in 0..7")
-    if p["isurf"] not in (0, 1, 2):
-        raise NotImplementedError("land BRDF/BPDF surfaces (-SURF.Type >= 3) are SURVEY 8f row f4 (next)")
+    if p["isurf"] not in (0, 1, 2, 3, 4, 5, 6, 7):
+        raise SosProcError("-SURF.Type must be in 0..7")
     if p["rho"] == _D:
         raise SosProcError("-SURF.Alb must be defined")
     if p["aot_ref"] == _D:
@@ -463,21 +463,36 @@ def sos_proc(aer_phase=None, device=0, **kw):
 
     # --- surface (SOS_PREPA_OS.F:479-497)
     isurf = int(p["isurf"])
-    igli, ifresnel, imat = int(isurf == 1), int(isurf == 2), int(isurf == 1)
+    igli, ifresnel, imat = int(isurf == 1), int(isurf == 2), int(isurf == 1 or isurf >= 3)
     rsurf = None
-    if isurf in (1, 2) and p["surf_ind"] == _D:
-        raise SosProcError("-SURF.Ind must be defined for sea surfaces")
+    land = None
+    if (isurf in (1, 2) or isurf >= 4) and p["surf_ind"] == _D:
+        raise SosProcError("-SURF.Ind must be defined for sea surfaces and BPDF models")
+    if isurf >= 3:
+        if _D in (p["k0_roujean"], p["k1_roujean"], p["k2_roujean"]):
+            raise SosProcError("-SURF.Roujean.K0/K1/K2 must be defined for -SURF.Type >= 3")
+        if isurf == 6:                                    # the reference's own SOS_PROC refuses it with this message
+            raise SosProcError("The Nadal's BPDF model is not supported ==> Select another surface model")
+        if isurf == 7 and p["coef_c_maignan"] == _D:
+            raise SosProcError("-SURF.Maignan.C must be defined for -SURF.Type 7")
+        land = _surface.land_model(isurf, p["k0_roujean"], p["k1_roujean"], p["k2_roujean"], p["alpha_nadal"], p["beta_nadal"],
+                                   p["coef_c_maignan"])
     lta = ta == 0.0 or piztr == 0.0                                                  # SOS.F:541-550: IBORM = 2 without aerosols
     iborm = min(2, os_nb) if lta else os_nb
     if isurf == 1:
         if p["wind"] == _D:
             raise SosProcError("-SURF.Glitter.Wind must be defined")
         rsurf = _surface.glitter_matrices(mu, ga, p["wind"], p["surf_ind"], os_nb, os_ns, os_nm, device=device)["rsurf"]
-        if iborm < os_nb:
-            rsurf = rsurf[:iborm + 1].contiguous()
+    if land is not None:
+        try:
+            rsurf = _surface.land_matrices(land, mu, ga, p["surf_ind"] if isurf >= 4 else 1.0, os_nb, os_ns, os_nm, device=device)
+        except ValueError as e:
+            raise SosProcError(str(e), ier=-1)
+    if rsurf is not None and iborm < os_nb:
+        rsurf = rsurf[:iborm + 1].contiguous()
 
     ctx = SosContext(mu, ga, n0, alpha, beta, gamma, zeta, iborm_max=iborm, ro=p["rho"], imat_surf=imat,
-                     ifresnel=ifresnel, ind_surf=p["surf_ind"] if isurf else 1.34, ron=MDF_DEFAULT,
+                     ifresnel=ifresnel, ind_surf=p["surf_ind"] if isurf in (1, 2) or isurf >= 4 else 1.34, ron=MDF_DEFAULT,
                      ipolar=int(p["ipolar"]), igmax=igmax, rsurf=rsurf, device=device)
     try:
         # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device, one fused solve, one aggregate
@@ -528,7 +543,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
         tau_agg, tauout_agg = float(fin["ttot_tronc"][0]), float(fin["tauout"][0])
         ttot_vrai_agg = float(fin["ttot_vrai"][0])
         phi_fin, theta_fin, up, dn = trphi_tables(ctx, rec[0], nf, tau_agg, tauout_agg, itrphi, p["phios"], p["pas_phi"],
-                                                  igli, p["wind"] if igli else 0.0)
+                                                  igli, p["wind"] if igli else 0.0, land=land)
         emoins, eplus = float(fin["emoins"][0]), float(fin["eplus"][0])
         resbin = str(p["ficsos_res_bin"]).strip()
         resroot = str(p["resroot"]).strip()

@@ -293,7 +293,7 @@ class SosContext:
                                                _ptr(o_rec), _ptr(o_scal), self._stream()), "sosgpu_aggregate")
         return o_rec, o_scal
 
-    def trphi(self, rec, nf, tau, tauout, phis_rad, igli=0, wind=0.0):
+    def trphi(self, rec, nf, tau, tauout, phis_rad, igli=0, wind=0.0, land=None):
         """SOS_TRPHI + SOS_POLAR for a list of azimuths (radians).  rec: device tensor [>=nf][3][W]
         (aggregated records).  Returns a device tensor [nphi][7][W]: XIT, XQT, XUT, ANGDIFF, polarisation
         angle, polarisation rate, polarised radiance."""
@@ -301,8 +301,9 @@ class SosContext:
         phis = _dev_f64(np.atleast_1d(np.asarray(phis_rad, dtype=np.float64)), d)
         rec = rec.to(device=d, dtype=torch.float64).contiguous()
         out = torch.empty((phis.numel(), 7, self.w), dtype=torch.float64, device=d)
+        lp = None if land is None else C.byref(land)          # capi.Land: direct term of the land model (-SURF.Type 3..7)
         capi.check(capi.lib().sosgpu_trphi(self._h, int(nf), _ptr(rec), float(tau), float(tauout), phis.numel(),
-                                           _ptr(phis), int(igli), float(wind), _ptr(out), self._stream()), "sosgpu_trphi")
+                                           _ptr(phis), int(igli), float(wind), lp, _ptr(out), self._stream()), "sosgpu_trphi")
         return out
 
     def close(self):
