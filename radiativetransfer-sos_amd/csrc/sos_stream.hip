@@ -195,6 +195,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     double sign = -1.;
     int red_slot = 0;
     int nord = 0;
+#ifdef SOS_PROFILE_PHASES
+    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 stage wait, 1 fix-up, 2 gemm, 3 write-back, 4 sweeps, 5 store, 6 pass end + tests, 7 order-1 passes
+#endif
+    PH_T0();
     for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
         sign = -sign;
         // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239); called by every thread
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                 if (!O1 && up && active) xi = xin[chk * KHM + kk];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if (!O1) PH(0);
                 if (!O1) {
                     // homogeneous part of the up-going rows: X+ = Q + P Xin, P running from the bottom level upwards
                     if (up && active) {
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                         if (cnt & 1) fix_block<1, FS, NS>(q, qa, P, xi);
                     }
                     __syncthreads();
+                    PH(1);
                     // source function of order ig for the levels of the chunk (SOS_FSOURCE_ORDREIG)
                     v4d acc[2][RTWH][CT];
 #pragma unroll
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                     else if (tile_a) contract(std::integral_constant<int, 1>());
                     else if (fold) __syncthreads();
                     __syncthreads();             // every wave has read the chunk
+                    PH(2);
                     {
                         double *wb = cbuf + (lane & 15) * FS + (lane >> 4);
 #pragma unroll
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                         }
                     }
                     __syncthreads();
+                    PH(3);
                 }
                 // formal solution of the chunk, in place (SOS_INTEGR_EPOPT)
                 if (active && !up) {
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                     }
                 }
                 __syncthreads();
+                if (!O1) PH(4);
                 // the chunk [Q+ | X-] of this order goes back to the scratch (levels l0..L only)
                 {
                     const int units = nlev * FS / 2;
@@ -393,6 +402,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
 #pragma unroll 1
                     for (; u < units; u += NTH) dst[u] = src[u];
                 }
+                if (O1) PH(7); else PH(5);
             }
             // after the last chunk: inflow of every chunk from the ground value upwards, Xin(c-1) = A(c) + B(c) Xin(c)
             if (active && up) {
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
         }
         if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
         nord = s + 1;
+        PH(6);
         int pf2 = 0;                                                                 // SOS_ARRET_FOURIER
         if (active) {
             const double a3 = fabs(i3);
@@ -505,6 +516,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     }
     for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
     if (t == 0) bn.norders[b] = nord;
+#ifdef SOS_PROFILE_PHASES
+    if (bn.phase && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&bn.phase[(size_t)b * 8 + k], ph_acc[k]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
