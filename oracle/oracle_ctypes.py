@@ -97,6 +97,12 @@ def sos_os(rmu, ga, os_nb, h, xdel, ydel, alpha, beta, gamma, zeta, *, n0, tetas
                 ig_counts=ig_last[:f].copy())
 
 
+def stop_margin():
+    """Tie audit of the last sos_os call: min |Z1/threshold - 1| over all its stop decisions (sos_oracle.c audit)."""
+    lib().sos_oracle_stop_margin.restype = C.c_double
+    return lib().sos_oracle_stop_margin()
+
+
 def profile_rescale(h, xdel, ydel, a_tronc, piz, piztr, os_nb):
     h = np.array(h, dtype=np.float64)
     xdel = np.array(xdel, dtype=np.float64)

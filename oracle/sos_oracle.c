@@ -376,6 +376,20 @@ static void fsource_diff_fresnel1(const geom_t *g, int is, double f11sun, double
 }
 
 /* one term of SOS_PARAM_CONV, SOS_OS.F:3434-3453 */
+/* Tie audit ("near-threshold ties need a documented policy"): every stop decision of the last
+ * sos_oracle_os call records how far the tested value was from its threshold, |Z1/threshold - 1|; the minimum is read
+ * with sos_oracle_stop_margin().  A decision closer to its threshold than the rounding difference between two correct
+ * implementations (about 1e-12) could go either way: the parity fixtures are required to stay far from that. */
+static double g_stop_margin = 1e300;
+static void audit(double z1, double thr)
+{
+    if (thr > 0. && z1 > 0.) {
+        const double m = fabs(z1 / thr - 1.);
+        if (m < g_stop_margin) g_stop_margin = m;
+    }
+}
+double sos_oracle_stop_margin(void) { return g_stop_margin; }
+
 static double conv_term(double a, double d, double gg, double x3, double z1)
 {
     if (a != 0.0 && d != 0.0 && x3 != 0.0) {
@@ -402,6 +416,7 @@ int sos_oracle_os(int n, const double *mu, const double *ga_in, int os_nb, int n
     const int W = 2 * n + 1, L = nt + 1;
     const size_t FS = (size_t)W * L;
     int i, j, k, is, ig, ier = 0;
+    g_stop_margin = 1e300;
     g->n = n; g->nt = nt; g->L = L; g->W = W;
     g->rmu = calloc(W, sizeof(double));
     g->ga = calloc(W, sizeof(double));
@@ -601,6 +616,7 @@ int sos_oracle_os(int n, const double *mu, const double *ga_in, int os_nb, int n
                     z1 = conv_term(V(b1, k), V(e1, k), V(h1, k), V(q3, k), z1);
                     z1 = conv_term(V(c1, k), V(f1, k), V(p1, k), V(u3, k), z1);
                 }
+                audit(z1, SEUIL_CV_SG);
                 if (!(z1 > SEUIL_CV_SG)) { /* SOS_AJOUT_QUEUE :3955-4015 */
                     for (j = -n; j <= n; j++) {
                         if (j == 0) continue;
@@ -641,6 +657,7 @@ int sos_oracle_os(int n, const double *mu, const double *ga_in, int os_nb, int n
                 z1 = fmax(z1, fabs(FLD(q1, ind, k)));
                 z1 = fmax(z1, fabs(FLD(u1, ind, k)));
             }
+            audit(z1, SEUIL_VALDIF);
             if (!(z1 > SEUIL_VALDIF)) break;
             z1 = 0.; /* SOS_ARRET_DIFFUS_2 :3626-3656 */
             for (k = -n; k <= n; k++) {
@@ -650,6 +667,7 @@ int sos_oracle_os(int n, const double *mu, const double *ga_in, int os_nb, int n
                 if (V(q3, k) != 0.0) z1 = fmax(z1, fabs(FLD(q1, ind, k) / V(q3, k)));
                 if (V(u3, k) != 0.0) z1 = fmax(z1, fabs(FLD(u1, ind, k) / V(u3, k)));
             }
+            audit(z1, SEUIL_SUMDIF);
             if (!(z1 > SEUIL_SUMDIF)) break;
             if (!(ig < igmax)) break; /* :1406 */
         }
@@ -712,6 +730,7 @@ int sos_oracle_os(int n, const double *mu, const double *ga_in, int os_nb, int n
                 if (V(u5, j) != 0.0) z1 = fmax(z1, fabs(V(u3, j) / V(u5, j)));
                 if (V(i5, j) != 0.0) z1 = fmax(z1, fabs(V(i3, j) / V(i5, j)));
             }
+            audit(z1, SEUIL_SF);
             if (!(z1 > SEUIL_SF)) break;
         }
     }

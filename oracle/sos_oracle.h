@@ -46,6 +46,10 @@ int sos_oracle_os(int n, const double *mu, const double *ga, int os_nb, int nt,
                   double zout, int igmax, int iborm, int ipolar, const float *rsurf,
                   double *rec, int *n_orders, int *ig_last, double *emoins, double *eplus);
 
+/* Tie audit: minimum over every stop decision (SOS_PARAM_CONV, SOS_ARRET_DIFFUS_1/2, SOS_ARRET_FOURIER) of the last
+ * sos_oracle_os call of |tested value / threshold - 1|. */
+double sos_oracle_stop_margin(void);
+
 /* SOS.F:523-550: delta-truncation rescale of a profile (in place) and IBORM choice.
  * Returns IBORM (os_nb, or 2 when no aerosol).  h/xdel/ydel: [nt+1]. */
 int sos_oracle_profile_rescale(int nt, double a_tronc, double piz, double piztr, int os_nb,

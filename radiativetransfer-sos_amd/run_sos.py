@@ -8,16 +8,18 @@ SOS_PROC.F:1168-1204).  Behind that surface the hot path runs on the GPU through
     angles (host)  ->  [aerosol expansion: given]  ->  profile (host)  ->  SOS.F rescale (host)
       -> sosgpu_glitter (ISURF=1) -> sosgpu_noyaux -> sosgpu_os_solve -> sosgpu_aggregate -> sosgpu_trphi
 
-Scope of this round: everything upstream of the hot path that the reference computes from
-physics tables is NOT rebuilt -- Mie/size distributions (`-AER.*` models) and CKD gas absorption
-(`-AP.AbsProfile.Type` != 7) raise NotImplementedError.  Supported: no-aerosol atmospheres (`-AER.AOTref 0`) or
-a caller-supplied phase-matrix expansion (extension keyword `aer_phase`, not in the reference), exponential
-molecular/aerosol profiles without gas (`-AP.AerProfile.Type 1`, `-AP.AbsProfile.Type 7`), surfaces
-`-SURF.Type` 0 (Lambert), 1 (Lambert + Cox-Munk glitter), 2 (Lambert + flat-sea Fresnel).
+Scope.  Supported: gas absorption by the CKD method (`-AP.AbsProfile.Type` 0..6, both
+`-SOS.AbsModeCKD` modes, all bins of a band solved in one batch) or none (7); aerosols given by the reference's own
+`-AER.UserFile` (an Aerosols.txt) or by the extension keyword `aer_phase`, or none; exponential profiles
+(`-AP.AerProfile.Type 1`); surfaces `-SURF.Type` 0 (Lambert), 1 (+ Cox-Munk glitter), 2 (+ flat sea), 3 (Roujean),
+4 / 5 / 7 (Roujean + Rondeaux-Herman / Breon / Maignan); `-SOS.Trans`, `-SOS.Flux`, `SOS_Result.bin` files.
+Not built: the aerosol MODELS (`-AER.Model`: Mie, WMO, Shettle & Fenn, bimodal: SURVEY 8f row f2), the aerosol layer
+profile (`-AP.AerProfile.Type 2`, whose reference output depends on an unassigned variable), `-SURF.Type 6` (Nadal), which
+the reference's SOS_PROC refuses as well.
 
 Differences from the reference script that are deliberate: errors raise exceptions instead of being
 lost in an `intent(in)` `ier`; `gen_sos_output` imports `ceil` and uses `and` (the reference has `1 & updown == 2`);
-no files are written unless asked (`-SOS.ResBin` path given through `write_result_bin`).
+files are written only when `-SOS_Main.ResRoot` is given (RESROOT/SOS/SOS_Result.bin, the -SOS.Trans / -SOS.Flux files).
 """
 import math
 import os
@@ -621,13 +623,56 @@ def write_result_bin(path, rec):
             f.write(m + payload + m)
 
 
+_HDR_SEP = "#" + "-" * 101 + "\n"
+_HDR_COLUMNS = [           # (name, description lines) of the SOS_Up.txt / SOS_Down.txt columns (binding/run_sos.py:255-270)
+    ("VZA", ["Viewing Zenith Angle (in degrees)"]),
+    ("SCA_ANG", ["Scattering angle (in degrees)"]),
+    ("I", ["Stokes parameter I at output altitude z (in sr-1)",
+           "normalised to the extraterrestrial solar irradiance (PI * L(z) / Esun)",
+           "normalised to the extraterrestrial solar irradiance"]),
+    ("Q", ["Stokes parameter Q at output altitude z (in sr-1)", "normalised to the extraterrestrial solar irradiance "]),
+    ("U", ["Stokes parameter U at output altitude z (in sr-1)", "normalised to the extraterrestrial solar irradiance "]),
+    ("POL_ANG", ["Polarization angle (in degrees). Note: if undefined the value is -999.00"]),
+    ("POL_RATE", ["Degree of polarization (in %)"]),
+    ("IPOL", ["Polarized intensity at level z (in sr-1)",
+              "normalised to the extraterrestrial solar irradiance (PI * Lpol(z) / Esun)"]),
+]
+
+
+def gen_hdr_sos_output(sos_view, updown, zalt):
+    """Header of SOS_Up.txt (updown = 1) / SOS_Down.txt (2), the text of binding/run_sos.py:219-278.  One deliberate
+    difference: the reference tests `sosView == 1 & updown == 2` (operator precedence makes it always false); here the
+    down-looking, fixed-azimuth file gets the 'Viewing direction' wording the reference meant it to have."""
+    plane = sos_view == 1
+    lines = ["#%s RADIANCE FIELD VERSUS %sVIEWING ZENITH ANGLE\n" % ("UPWARD" if updown == 1 else "DOWNWARD",
+                                                                      "THE AZIMUTH ANGLE AND " if plane else ""),
+             "# (RELATIVE AZIMUTH AND ALTITUDE ARE FIXED)\n" if plane else "# (ALTITUDE IS FIXED)", _HDR_SEP]
+    if plane:
+        lines.append("# Relative azimuth (degrees) :\n#\n")
+    who = "Viewing direction" if (plane and updown == 2) else "Satellite"
+    lines += ["#      Relative azimuth convention :\n",
+              "#        180 deg <-> %s and Sun in the same half-plane\n" % who,
+              "#          0 deg <-> %s and Sun in opposite half-planes with respect to the zenith direction\n#\n" % who,
+              "# Value of the selected altitude for the output (km) : %s\n#\n" % zalt, "# Columns parameters :\n"]
+    cols = ([("PHI", ["Relative azimuth Angle (in degrees)"])] if not plane else []) + _HDR_COLUMNS
+    for name, desc in cols:
+        lines.append("#   %-8s:  %s\n" % (name, desc[0]))
+        lines += ["#              %s\n" % d for d in desc[1:]]
+    lines.append(_HDR_SEP)
+    lines.append("#   %sVZA     SCA_ANG        I              Q              U       POL_ANG  POL_RATE    IPOL\n"
+                 % ("" if plane else "PHI      "))
+    lines.append("#%s(degrees) (degrees)  (no unit)      (no unit)      (no unit)   (degrees) (pcts)  (no unit)\n"
+                 % ("" if plane else "(degrees) "))
+    return "".join(lines)
+
+
 def gen_sos_output(rep_out, sos_view, updown, zalt, nblum, pas_phi, phi, vza, sca_ang, i_out, q_out, u_out,
                    pol_ang_out, pol_rate_out, l_pol_out):
-    """run_sos.py:280-317 (SOS_Up.txt / SOS_Down.txt data block; header abridged to the column titles)."""
+    """run_sos.py:280-317: SOS_Up.txt / SOS_Down.txt (header + data block).  Fixed-azimuth view: the phi + 180 half plane
+    first (negated zenith angles, reversed order), then the phi half plane."""
     name = "SOS_Up.txt" if updown == 1 else "SOS_Down.txt"
     with open(os.path.join(rep_out, name), "w") as fic:
-        az = "PHI      " if sos_view == 2 else ""
-        fic.write("#   %sVZA     SCA_ANG        I              Q              U       POL_ANG  POL_RATE    IPOL\n" % az)
+        fic.write(gen_hdr_sos_output(sos_view, updown, zalt))
         if sos_view == 1:
             for it in range(nblum - 1, -1, -1):
                 fic.write("  %7.2f %7.2f  %13.6e  %13.6e  %13.6e  %7.2f %7.2f %13.6e\n" % (
