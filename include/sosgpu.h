@@ -233,6 +233,15 @@ int  sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, dou
 int  sosgpu_absprofile(int device, int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro,
                        double *d_tabs, void *stream);
 
+/* Replaces SOS_MIE + SOS_FPHASE_MIE (src/SOS_MIE.F:205, :801) for a whole grid of size parameters, no MIE cache file:
+ *   xmu[2 nbmu + 1]  cosines RMU(-nbmu:nbmu) of the Mie angle set (host); rn, in: refractive index (in <= 0)
+ *   alphas[nalpha]   size parameters (host; the reference's grid: steps 1e-4 ... 1 growing with alpha, SOS_MIE.F:437-443)
+ *   d_rec[nalpha][4 + 3 (2 nbmu + 1)]  REAL*4 records {alpha, Qext, Qsca, 0, Imie(-nbmu:nbmu), Qmie(..), Umie(..)}
+ *   d_g[nalpha]      asymmetry factor (double, as the file keeps it)
+ * SOSGPU_E_UNSUPPORTED when 2 alpha + 24 coefficients do not fit LDS (alpha > ~840).  Synchronous. */
+int  sosgpu_mie(int device, int nbmu, const double *xmu, double rn, double in, int nalpha, const double *alphas,
+                float *d_rec, double *d_g, void *stream);
+
 /* Diagnostic hook: hand the context a device buffer [nb][8] of uint64 that builds compiled with
  * -DSOS_PROFILE_PHASES fill with per-phase cycle sums of the solver kernel (0 order-1 fill, 1 formal solution,
  * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.

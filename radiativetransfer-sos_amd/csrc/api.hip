@@ -843,6 +843,40 @@ extern "C" int sosgpu_absprofile(int device, int nb, int nlev, int nterm, const 
     return SOSGPU_OK;
 }
 
+extern "C" int sosgpu_mie(int device, int nbmu, const double *xmu, double rn, double in, int nalpha, const double *alphas,
+                          float *d_rec, double *d_g, void *stream)
+{
+    if (nbmu < 1 || nbmu > 100 || !xmu || nalpha < 1 || !alphas || !d_rec || !d_g) return SOSGPU_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const int W = 2 * nbmu + 1;
+    double amax = 0.;
+    for (int i = 0; i < nalpha; i++) { if (!(alphas[i] > 0.)) return SOSGPU_E_ARG; amax = std::max(amax, alphas[i]); }
+    char *buf = nullptr;
+    HIPCHK(hipMalloc((void **)&buf, (size_t)(W + nalpha) * sizeof(double) + 64));
+    double *d_xmu = (double *)buf, *d_al = d_xmu + W;
+    int32_t *d_err = (int32_t *)(d_al + nalpha);
+    int32_t err = 0;
+    hipError_t e = hipMemcpyAsync(d_xmu, xmu, W * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_al, alphas, nalpha * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, sizeof(int32_t), st);
+    int rc = 0;
+    if (e == hipSuccess) {
+        rc = launch_mie(nalpha, nbmu, d_xmu, rn, in, d_al, amax, d_rec, d_g, d_err, st);
+        if (rc == 0) e = hipGetLastError();
+    }
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(&err, d_err, sizeof err, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (rc == -3) return SOSGPU_E_UNSUPPORTED;
+    if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
+    HIPCHK(e);
+    return err ? SOSGPU_E_UNSUPPORTED : SOSGPU_OK;
+}
+
 // Diagnostic: per-bin phase cycle counters [nb][8] (filled only by builds with -DSOS_PROFILE_PHASES).
 extern "C" int sosgpu_debug_phase_buffer(sosgpu_ctx *cx, unsigned long long *d_phase)
 {

@@ -53,3 +53,8 @@ void launch_profile(const ProfileArgs &a, hipStream_t st);
 // SOS_ABSPROFILE for nb bins: ik[nb][8] 1-based term per gas, xk[8][nterm][nlev-1], ro[8][nlev-1] -> tabs[nb][nlev]
 void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro, double *d_tabs,
                        hipStream_t st);
+
+// Mie records of a size-parameter grid (mie.hip): rec[nalpha][4 + 3 (2 nbmu + 1)] floats, g[nalpha]; returns 0, -2 (HIP) or -3
+// (alpha_max beyond the LDS-resident coefficient arrays)
+int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, const double *d_alphas, double alpha_max,
+               float *d_rec, double *d_g, int32_t *d_err, hipStream_t st);

@@ -13,7 +13,8 @@ Scope.  Supported: gas absorption by the CKD method (`-AP.
 `-AER.UserFile` (an Aerosols.txt) or by the extension keyword `aer_phase`, or none; exponential profiles
 (`-AP.AerProfile.Type 1`); surfaces `-SURF.Type` 0 (Lambert), 1 (+ Cox-Munk glitter), 2 (+ flat sea), 3 (Roujean),
 4 / 5 / 7 (Roujean + Rondeaux-Herman / Breon / Maignan); `-SOS.Trans`, `-SOS.Flux`, `SOS_Result.bin` files.
-Not built: the aerosol MODELS (`-AER.Model`: Mie, WMO, Shettle & Fenn, bimodal: SURVEY 8f row f2), the aerosol layer
+Aerosol models `-AER.Model 0` (mono-modal log-normal / Junge) and 3 (bimodal log-normal): Mie theory on the GPU
+(aerosols.py, csrc/mie.hip).  Not built: the WMO / Shettle & Fenn / external-data / mixture models, the aerosol layer
 profile (`-AP.AerProfile.Type 2`, whose reference output depends on an unassigned variable), `-SURF.Type 6` (Nadal), which
 the reference's SOS_PROC refuses as well.
 
@@ -391,9 +392,10 @@ def sos_proc(aer_phase=None, device=0, **kw):
     if p["aot_ref"] == _D:
         raise SosProcError("-AER.AOTref must be defined")
     user_aer = str(p["ficuser_aer"]).strip()
-    if p["aot_ref"] != 0.0 and aer_phase is None and user_aer == "NO_USER_AEROSOLS":
-        raise NotImplementedError("aerosol models (-AER.*: Mie, WMO, S&F, bimodal) are SURVEY 8f row f2 (next); "
-                                  "pass the phase-matrix expansion through aer_phase=")
+    use_model = p["aot_ref"] != 0.0 and aer_phase is None and user_aer == "NO_USER_AEROSOLS"
+    if use_model and p["imod_aer"] not in (0, 3):
+        raise NotImplementedError("-AER.Model %s (WMO, Shettle & Fenn, external data, user mixtures) is not built: give the "
+                                  "phase-matrix expansion through -AER.UserFile or aer_phase=" % p["imod_aer"])
     if p["hr"] == _D:
         raise SosProcError("-AP.HR must be defined")
     itrphi = p["itrphi"]
@@ -418,7 +420,24 @@ def sos_proc(aer_phase=None, device=0, **kw):
     # --- aerosols: none, a user Aerosols.txt (-AER.UserFile, SOS_PROC.F:2883-2934: SOS_AEROSOLS is not run, the file
     # is read by SOS_PREPA_OS.F:666-700), or a given expansion (stands for SOS_AEROSOLS -> Aerosols.txt)
     coef_tronca_out = None
-    if p["aot_ref"] != 0.0 and aer_phase is None:
+    ta_model = None
+    if use_model:
+        # SOS_AEROSOLS at the reference wavelength, and again at the simulation wavelength when they differ: the optical
+        # thickness scales with the extinction cross sections (SOS_PROC.F:2883-3060)
+        from . import aerosols as _aer
+        if p["waref_aot"] == _D:
+            raise SosProcError("-AER.Waref must be defined")
+        try:
+            aer_phase = _aer.aerosols(p, p["waref_aot"], p["aot_ref"], nb_mie, os_nb, at_waref=True, device=device)
+            ta_model = float(p["aot_ref"])
+            if p["wa_simu"] != p["waref_aot"]:
+                k_ref = aer_phase["kmat1"]
+                aer_phase = _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device)
+                ta_model = (aer_phase["kmat1"] / k_ref) * p["aot_ref"]
+        except _aer.AerosolError as e:
+            raise SosProcError(str(e), ier=-1)
+        coef_tronca_out = aer_phase["coef_tronca"]
+    elif p["aot_ref"] != 0.0 and aer_phase is None:
         if not os.path.exists(user_aer):
             raise SosProcError("-AER.UserFile %s not found" % user_aer)
         aer_phase = read_aerosols_file(user_aer, os_nb)
@@ -428,7 +447,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
         alpha = beta = gamma = zeta = np.zeros(os_nb + 1)
         piz, piztr, a_tronc = 0.0, 0.0, 0.0
     else:
-        ta = float(p["aot_ref"])
+        ta = float(p["aot_ref"]) if ta_model is None else ta_model
         alpha, beta, gamma, zeta = (np.asarray(aer_phase[k], dtype=np.float64) for k in ("alpha", "beta", "gamma", "zeta"))
         if len(beta) != os_nb + 1:
             raise SosProcError("aer_phase arrays must have OS_NB+1 = %d entries" % (os_nb + 1))
@@ -551,6 +570,9 @@ def sos_proc(aer_phase=None, device=0, **kw):
         resroot = str(p["resroot"]).strip()
         if resroot:                                   # SOS_PROC.F:1342-1500: results under RESROOT/SOS
             os.makedirs(os.path.join(resroot, "SOS"), exist_ok=True)
+            if use_model:
+                write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()), aer_phase, aer_phase["kmat1"],
+                                    aer_phase["kmat2"])
             write_result_bin(os.path.join(resroot, "SOS", resbin), rec[0, :nf].cpu().numpy())
     finally:
         ctx.close()
