@@ -1,22 +1,20 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of the bench command on the GPU box (run through gpurun from the repo root):
-#   1. --kernel-trace --stats        -> per-kernel durations
+#   1. --kernel-trace --stats        -> per-kernel durations (headline + realistic mix + aggregate kernels)
 #   2. --pmc FETCH_SIZE              -> HBM/fabric read bytes   (separate pass, kernel-trace only)
 #   3. --pmc WRITE_SIZE              -> HBM/fabric write bytes  (separate pass, kernel-trace only)
-# Outputs land under gpurun_out/prof/<tag>/; scripts/summarize_profiles.py turns them into profiles/<round>_*.
-set -e
-TAG=${1:-r01}
+#   4. --pmc MFMA busy counters
+#   5. --kernel-trace --stats of scripts/aux_kernels.py (noyaux, glitter, land, Mie, profile, absprofile, trphi kernels)
+# Outputs land under gpurun_out/prof/<tag>/; scripts/summarize_profiles.py turns them into profiles/<tag>_*.
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 ARGS="$REPO/bench.py --steps 3 --warmup 1 --no-cpu"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ARGS > $OUT/stats.log 2>&1
-echo stats done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
-echo fetch done
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ARGS > $OUT/write.log 2>&1
-echo write done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o mfma -- python3 $ARGS > $OUT/mfma.log 2>&1 || echo "mfma pass failed"
-echo mfma done
-find $OUT -name "*.csv" | head -20
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ARGS > $OUT/stats.log 2>&1 && echo stats done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ARGS > $OUT/fetch.log 2>&1 && echo fetch done
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ARGS > $OUT/write.log 2>&1 && echo write done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o mfma -- python3 $ARGS > $OUT/mfma.log 2>&1 && echo mfma done
+rocprofv3 --kernel-trace --stats -d $OUT/aux -o aux -- python3 $REPO/scripts/aux_kernels.py > $OUT/aux.log 2>&1 && echo aux done
+find $OUT -name "*.db" | head -20

@@ -27,7 +27,7 @@ def rows(db, q):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r02"
     bins = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 4096
     nt = int(sys.argv[sys.argv.index("--nt") + 1]) if "--nt" in sys.argv else 30
     src = os.path.join(ROOT, "gpurun_out", "prof", tag)
@@ -52,8 +52,10 @@ def main():
         r = rows(db, "select name, count(*), avg(counter_value) from pmc_events where counter_name = '%s' group by name order by avg(counter_value) desc" % counter)
         for name, n, mean in r:
             lines.append([name, counter, n, "%.3f" % mean, "%.4e" % (factor * mean * 1024.0)])
-            if name.startswith("void k_sos_os") or "k_sos_os" in name:
+            if "k_sos_os" in name:
                 summary["k_sos_os_%s_bytes" % pas] = factor * mean * 1024.0
+            if "k_sos_stream" in name:
+                summary["k_sos_stream_%s_bytes" % pas] = factor * mean * 1024.0
     with open(os.path.join(out, "%s_pmc_hbm.csv" % tag), "w", newline="") as f:
         f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu\n")
         f.write("# derived counters are in KiB per dispatch (mean over dispatches); gfx950 correction per MI355X_MICROARCH.md (HBM section):\n")
@@ -66,6 +68,22 @@ def main():
     with open(os.path.join(out, "%s_pmc_hbm.json" % tag), "w") as f:
         json.dump(summary, f, indent=1)
     print("hbm:", summary)
+    if "k_sos_stream_fetch_bytes" in summary and "k_sos_stream_write_bytes" in summary:
+        # the realistic-mix leg of the same command (bench.py run_realistic): read by bench.pmc_traffic("_realistic")
+        mix = dict(tag=tag, bins_per_gpu=bins, command=summary["command"], workload="realistic_mix",
+                   k_sos_os_bytes_per_launch=summary["k_sos_stream_fetch_bytes"] + summary["k_sos_stream_write_bytes"],
+                   fetch_bytes=summary["k_sos_stream_fetch_bytes"], write_bytes=summary["k_sos_stream_write_bytes"])
+        with open(os.path.join(out, "%s_pmc_hbm_realistic.json" % tag), "w") as f:
+            json.dump(mix, f, indent=1)
+    aux = os.path.join(src, "aux", "aux_results.db")
+    if os.path.exists(aux):
+        st = rows(aux, "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc")
+        with open(os.path.join(out, "%s_aux_kernel_stats.csv" % tag), "w", newline="") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python3 scripts/aux_kernels.py   (durations in ns; N = 41, OS_NB = 80, 4096 bins)\n")
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ns", "average_ns", "min_ns", "max_ns"])
+            for r in st:
+                w.writerow([r[0], r[1], r[2], "%.1f" % r[3], r[4], r[5]])
 
     db = os.path.join(src, "mfma", "mfma_results.db")
     if os.path.exists(db):
