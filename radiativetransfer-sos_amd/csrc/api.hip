@@ -345,7 +345,20 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
-        rc = big ? launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip) : launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
+        bn.s_begin = 0; bn.s_end = S1;
+        if (big) {
+            // The streamed kernel can run `opl` Fourier orders of every bin per launch (order-synchronous launches: every
+            // workgroup then streams the same source operator).  Measured on the realistic mix (profiles/r02_stream_experiments.txt):
+            // 1 order per launch 21.1k bins/s, all orders in one launch 21.9k -- the operator stream is not what binds, so one
+            // launch is the default; SOSGPU_STREAM_ORDERS_PER_LAUNCH = n selects n orders per launch (tests cover both).
+            int opl = 0;
+            if (const char *e = getenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH")) opl = atoi(e);
+            if (opl <= 0) opl = S1;
+            for (int s0 = 0; s0 < S1 && rc == 0; s0 += opl) {
+                bn.s_begin = s0; bn.s_end = std::min(S1, s0 + opl);
+                rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
+            }
+        } else rc = launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
         if (rc == -2) return SOSGPU_E_HIP;
         if (rc) return rc;
     }

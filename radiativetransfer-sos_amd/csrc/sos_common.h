@@ -62,11 +62,12 @@ struct SosBins {
     const double *prof, *zz;
     double *rec, *flux;
     int32_t *norders, *iglast;
-    // field-in-HBM variant (NT too large for LDS): per-bin scratch of scr_stride doubles laid out
-    // [lpb][FS] field | [lpb][NS] attenuations | [7][lpb] level vectors (FS, NS: strides of the variant, sos_os.hip)
+    // streamed-field variant (NT too large for LDS, sos_stream.hip): per-bin scratch of scr_stride doubles
     double *scratch;
     size_t scr_stride;
     int lpb;
+    int s_begin, s_end;          // streamed variant: Fourier orders s_begin <= s < s_end of this launch (order-synchronous
+                                 // launches keep the source operator of the order in L2 for every workgroup of an XCD)
     unsigned long long *phase;   // diagnostic builds only (SOS_PROFILE_PHASES): [nb][8] cycle sums per phase
 };
 

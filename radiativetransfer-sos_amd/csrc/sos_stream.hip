@@ -26,6 +26,9 @@
 #include "sos_dev.h"
 #include "kernels.h"
 
+#ifndef SOS_STREAM_NT
+#define SOS_STREAM_NT 2
+#endif
 namespace {
 constexpr int COLS = 32;      // levels per chunk (two 16-column MFMA tiles)
 constexpr int VPAD = 8;       // level vectors are stored with a +1 offset (entry e = level e-1) and a few spare entries
@@ -35,7 +38,8 @@ constexpr int VPAD = 8;       // level vectors are stored with a +1 offset (entr
 __host__ __device__ inline size_t stream_scratch_doubles(int nw, int rtw, int lpb)
 {
     const size_t fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw), khm = sos_khm(nw, rtw), nch = lpb / COLS;
-    const size_t d = (size_t)lpb * fs + (size_t)(lpb + 1) * ns + 7 * (size_t)(lpb + VPAD) + nch * (2 * khm + ns);
+    const size_t d = (size_t)lpb * fs + (size_t)(lpb + 1) * ns + 7 * (size_t)(lpb + VPAD) + nch * (2 * khm + ns) +
+                     2 * 64 * (size_t)nw + 8;                  // + state carried from one launch to the next (i4, i5 per thread)
     return (d + 15) & ~(size_t)15;
 }
 
@@ -54,12 +58,14 @@ __device__ __forceinline__ void fix_block(double *&q, const double *&qa, double 
 }
 
 // linear LDS-DMA copy of `units` 16-byte units global -> LDS (wave-uniform LDS base + lane * 16, exec-masked tail)
-template <int NTH>
+// AUX = 2: non-temporal (the field of a bin is read once per scattering order: it must not push the source operator, which
+// every workgroup of the XCD re-reads, out of L2)
+template <int NTH, int AUX>
 __device__ __forceinline__ void glds_copy(const double *g, double *l, int units, int t)
 {
     for (int u = t; u < units; u += NTH)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 2 * (size_t)u),
-                                         (__attribute__((address_space(3))) void *)(l + 2 * (size_t)(u - (t & 63))), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(l + 2 * (size_t)(u - (t & 63))), 16, 0, AUX);
 }
 
 // NW, RTWH, ZO, SURF: as k_sos_os (sos_os.hip).  Two workgroups per CU for NW = 4: while one waits for its chunk the other
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     double *xin = vec + (size_t)7 * VS;                   // [NCH][KHM]
     double *acf = xin + (size_t)NCH * KHM;                // [NCH][KHM]
     double *bcf = acf + (size_t)NCH * KHM;                // [NCH][NS]
+    double *state = bcf + (size_t)NCH * NS;               // [8 + 2 NTH]: status | has_aer | nord | ... | i4, i5 per thread
 
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool up = wv < HW;               // wave-uniform
@@ -126,9 +133,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     const int nchunk = (nt + COLS) / COLS;
     const double *pf = bn.prof + (size_t)b * 3 * bn.lp;
     double *recb = bn.rec + (size_t)b * S1 * 3 * W;
+    // Order-synchronous launches: a launch runs the Fourier orders [s_begin, s_end) of every bin, so that all workgroups of
+    // an XCD stream the SAME source operator (240 KB at N = 41) from L2 instead of ~20 different ones from the fabric.  The
+    // scratch keeps the bin constants (level vectors, attenuations, link factors) and the little state a bin carries from
+    // order to order (running Fourier sums I4, I5 of every row, SOS_OS.F:1460-1473) between launches.
+    const bool first = bn.s_begin == 0;
+    if (!first && uniform_f64(state[0]) != 0.) return;          // the Fourier series of this bin has already stopped
+    const double htot = uniform_f64(pf[nt]), h0 = uniform_f64(pf[0]);
+    const double hlo = uniform_f64(pf[jlo]), hhi = uniform_f64(pf[jhi]);
+    int has_aer;
 
     // ---- per-bin set-up: level vectors, attenuation table, chunk link factors -> scratch -------------------------------
     __syncthreads();
+  if (first) {
     if (!SURF && t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
     if (SURF) for (int i = t; i < 3 * NS + 2; i += NTH) gnd[i] = 0.;
     for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
@@ -146,9 +163,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     // levels above nt of the last chunk stay zero in the scratch for the whole solve (they are loaded, never stored)
     for (size_t i = (size_t)(nt + 1) * FS + t; i < (size_t)nchunk * COLS * FS; i += NTH) fld[i] = 0.;
     __syncthreads();
-    const double htot = uniform_f64(hh[nt + 1]);
-    const double h0 = uniform_f64(hh[1]);
-    const double hlo = uniform_f64(hh[jlo + 1]), hhi = uniform_f64(hh[jhi + 1]);
     int aer_l = 0;
     for (int e = t; e < VS; e += NTH) {
         const int i = e - 1;
@@ -159,7 +173,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
         v_cxd[e] = ch * v_xd[e]; v_cyd[e] = ch * v_yd[e];
         if (i >= 0 && i <= nt && v_xd[e] != 0.) aer_l = 1;
     }
-    const int has_aer = uniform_i32(__syncthreads_or(aer_l));
+    has_aer = uniform_i32(__syncthreads_or(aer_l));
+    if (t == 0) { state[0] = 0.; state[1] = has_aer; }
     for (int i = t; i < nt * N; i += NTH)
         att[(size_t)(i / N + 1) * NS + i % N] = 1.0 - exp(-dtau[i / N + 1] / cx.mu[i % N]);          // SOS_OS.F:2291,2335
     __syncthreads();
@@ -177,6 +192,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
         if (cq > 0) P = P - P * att[(size_t)l0 * NS + j];                                           // layer l0 - 1
         bcf[cq * NS + j] = P;
     }
+    __syncthreads();
+  } else {
+    if (!SURF && t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
+    if (SURF) for (int i = t; i < 3 * NS + 2; i += NTH) gnd[i] = 0.;
+    for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
+    has_aer = uniform_i32((int)state[1]);
+    __syncthreads();
+  }
     const double e_sun = uniform_f64(exp(-htot / cx.mus));
     // ZO: attenuation from the bottom of its chunk up to the two output levels (up-going rows)
     double plo = 1., phi = 1.;
@@ -195,11 +218,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     double sign = -1.;
     int red_slot = 0;
     int nord = 0;
+    bool finished = false;
+    if (!first) {
+        i4 = state[8 + 2 * t]; i5 = state[8 + 2 * t + 1];
+        nord = bn.s_begin;
+        if (bn.s_begin & 1) sign = 1.;                   // sign = (-1)^s after the flip at the top of the loop
+    }
 #ifdef SOS_PROFILE_PHASES
     unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 stage wait, 1 fix-up, 2 gemm, 3 write-back, 4 sweeps, 5 store, 6 pass end + tests, 7 order-1 passes
 #endif
     PH_T0();
-    for (int s = 0; s <= iborm; ++s) {            // SOS_OS.F:872
+    const int s_last = min(iborm, bn.s_end - 1);
+    if (bn.s_begin > iborm) finished = true;
+    for (int s = bn.s_begin; s <= s_last; ++s) {  // SOS_OS.F:872
         sign = -sign;
         // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239); called by every thread
         const double *gop = SURF ? cx.mp_gnd + (size_t)s * cx.rtph * cx.ks2h * 128 : nullptr;
@@ -262,8 +293,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                 __syncthreads();                  // the previous chunk has left LDS
                 // stage the chunk: field of order ig-1 (32 levels; the scratch is zero beyond nt), attenuations of layers
                 // l0-1 .. l0+30, level vectors of levels l0-1 .. l0+38
-                if (!O1) glds_copy<NTH>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
-                glds_copy<NTH>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
+                if (!O1) glds_copy<NTH, SOS_STREAM_NT>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
+                glds_copy<NTH, 0>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
                 for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + l0 + e % VL];
                 double xi = 0.;
                 if (!O1 && up && active) xi = xin[chk * KHM + kk];
@@ -397,7 +428,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
 #pragma unroll 1
                     for (; u + 3 * NTH < units; u += 4 * NTH) {
                         const v2d a0 = src[u], a1 = src[u + NTH], a2 = src[u + 2 * NTH], a3 = src[u + 3 * NTH];
+#if SOS_STREAM_NT
+                        __builtin_nontemporal_store(a0, &dst[u]); __builtin_nontemporal_store(a1, &dst[u + NTH]);
+                        __builtin_nontemporal_store(a2, &dst[u + 2 * NTH]); __builtin_nontemporal_store(a3, &dst[u + 3 * NTH]);
+#else
                         dst[u] = a0; dst[u + NTH] = a1; dst[u + 2 * NTH] = a2; dst[u + 3 * NTH] = a3;
+#endif
                     }
 #pragma unroll 1
                     for (; u < units; u += NTH) dst[u] = src[u];
@@ -512,10 +548,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
             if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf2 = 1;
         }
         pf2 = block_or_bits<NW>(pf2, reinterpret_cast<int *>(red), wv, lane, red_slot);
-        if (!pf2) break;                                                             // SOS_OS.F:1585
+        if (!pf2 || s == iborm) { finished = true; break; }                          // SOS_OS.F:1585
     }
-    for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
-    if (t == 0) bn.norders[b] = nord;
+    if (finished) {
+        for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
+        if (t == 0) { bn.norders[b] = nord; state[0] = 1.; }
+    } else {                                             // more orders follow in the next launch
+        state[8 + 2 * t] = i4; state[8 + 2 * t + 1] = i5;
+        if (t == 0) bn.norders[b] = nord;
+    }
 #ifdef SOS_PROFILE_PHASES
     if (bn.phase && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&bn.phase[(size_t)b * 8 + k], ph_acc[k]);
 #endif
