@@ -38,7 +38,7 @@ constexpr int VPAD = 8;       // level vectors are stored with a +1 offset (entr
 __host__ __device__ inline size_t stream_scratch_doubles(int nw, int rtw, int lpb)
 {
     const size_t fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw), khm = sos_khm(nw, rtw), nch = lpb / COLS;
-    const size_t d = (size_t)lpb * fs + (size_t)(lpb + 1) * ns + 7 * (size_t)(lpb + VPAD) + nch * (2 * khm + ns) +
+    const size_t d = (size_t)lpb * fs + (size_t)(lpb + 1) * ns + 7 * (size_t)(lpb + VPAD) + nch * (2 * khm + 2 * ns) +
                      2 * 64 * (size_t)nw + 8;                  // + state carried from one launch to the next (i4, i5 per thread)
     return (d + 15) & ~(size_t)15;
 }
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
     double *xin = vec + (size_t)7 * VS;                   // [NCH][KHM]
     double *acf = xin + (size_t)NCH * KHM;                // [NCH][KHM]
     double *bcf = acf + (size_t)NCH * KHM;                // [NCH][NS]
-    double *state = bcf + (size_t)NCH * NS;               // [8 + 2 NTH]: status | has_aer | nord | ... | i4, i5 per thread
+    double *pmid = bcf + (size_t)NCH * NS;                // [NCH][NS] attenuation from the bottom level of a chunk to its middle
+    double *state = pmid + (size_t)NCH * NS;              // [8 + 2 NTH]: status | has_aer | nord | ... | i4, i5 per thread
 
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool up = wv < HW;               // wave-uniform
@@ -187,8 +188,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
         // chunk cq, direction j: attenuation from the chunk's bottom level up to its top level, times the layer above it
         const int cq = i / N, j = i % N;
         const int l0 = cq * COLS, L = min(l0 + COLS - 1, nt);
+        const int mid = l0 + (L - l0) / 2;           // the up-going waves fix levels L .. mid+1, the down-going waves mid .. l0
         double P = 1.0;
-        for (int k = L - 1; k >= l0; --k) P = P - P * att[(size_t)(k + 1) * NS + j];
+        for (int k = L - 1; k >= l0; --k) {
+            P = P - P * att[(size_t)(k + 1) * NS + j];
+            if (k == mid + 1) pmid[cq * NS + j] = P;  // attenuation from L up to level mid + 1
+        }
+        if (mid + 1 >= L) pmid[cq * NS + j] = 1.0;
         if (cq > 0) P = P - P * att[(size_t)l0 * NS + j];                                           // layer l0 - 1
         bcf[cq * NS + j] = P;
     }
@@ -296,19 +302,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                 if (!O1) glds_copy<NTH, SOS_STREAM_NT>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
                 glds_copy<NTH, 0>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
                 for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + l0 + e % VL];
-                double xi = 0.;
-                if (!O1 && up && active) xi = xin[chk * KHM + kk];
+                double xi = 0., pm = 1.;
+                if (!O1 && active) { xi = xin[chk * KHM + kk]; if (!up) pm = pmid[chk * NS + jj]; }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (!O1) PH(0);
                 if (!O1) {
-                    // homogeneous part of the up-going rows: X+ = Q + P Xin, P running from the bottom level upwards
-                    if (up && active) {
-                        double *q = cbuf + (size_t)(L - l0) * FS + rl;
-                        const double *qa = catt + (size_t)(L - l0) * NS + jj;      // layer L-1
-                        double P = 1.0;
-                        *q = xi;
-                        int cnt = nlev - 1;
+                    // homogeneous part of the up-going rows: X+ = Q + P Xin, P running from the bottom level upwards.  Shared
+                    // by all four waves: the thread of up-going row kk does levels L .. mid+1, the thread of the down-going
+                    // row with the same kk does levels mid .. l0 of that UP-going row, starting from the tabulated P(mid+1)
+                    if (active) {
+                        const int mid = l0 + (L - l0) / 2;
+                        const int lev = up ? L : mid + 1;              // level this thread starts from (already final there)
+                        double *q = cbuf + (size_t)(lev - l0) * FS + kk;          // row kk of the up-going half
+                        const double *qa = catt + (size_t)(lev - l0) * NS + jj;   // layer lev-1
+                        double P = up ? 1.0 : pm;                       // attenuation from L up to `lev`
+                        int cnt = up ? L - mid - 1 : (L > l0 ? mid - l0 + 1 : 0);
+                        if (cnt < 0) cnt = 0;
+                        if (up) *q = xi;                                // level L: Q = 0, X = Xin
 #pragma unroll 1
                         for (; cnt >= 8; cnt -= 8) fix_block<8, FS, NS>(q, qa, P, xi);
                         if (cnt & 4) fix_block<4, FS, NS>(q, qa, P, xi);
