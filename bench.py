@@ -325,7 +325,7 @@ def main():
                            bin_order="generation" if args.no_sort else "cost-sorted"),
                roofline=dict(bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
-                             kernel="k_sos_os<4,2,2,false,false,false>", kernel_ms=kern_ms, flops_per_launch=flops_exe,
+                             kernel="k_sos_os<4,2,2,false,false>", kernel_ms=kern_ms, flops_per_launch=flops_exe,
                              flops_counted="parity form (two 3N x 3Nw half systems, Nw = weighted directions) + rank-4 molecular form + formal solution, unpadded",
                              reference_algorithm_flops_per_launch=flops_ref,
                              reference_algorithm_tflops=flops_ref / (kern_ms * 1e-3) / 1e12))

@@ -38,8 +38,13 @@
 // form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded form with a few
 // scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one instantiation gave wrong down-going rows on
 // gfx950, so it is not used.
+#ifdef SOS_WIDE_REGS                                       // diagnostic build: 512-register form of the 4-wave CT = 4 variants
+#define SOS_MIN_WG(NW, CT) (((NW) == 4 && (CT) != 4) ? 2 : 1)
+#else
+#define SOS_MIN_WG(NW, CT) (((NW) == 4) ? 2 : 1)
+#endif
 template <int NW, int RTWH, int CT, bool ZO, bool SURF>
-__global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_os(const SosDev cx, const SosBins bn)
+__global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
     constexpr int NTH = 64 * NW, HW = NW / 2;
@@ -465,6 +470,9 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     if (cx.kh > sos_khm(nw, rtw) || cx.rtph * 16 < cx.kh) return SOSGPU_E_UNSUPPORTED;
     if (big) return SOSGPU_E_UNSUPPORTED;                  // streamed variant: launch_sos_stream (sos_stream.hip)
     const int zo = bn.jout != nullptr;
+#ifdef SOS_WIDE_REGS
+    if (nw == 8 && rtw == 1 && ct == 4) { nw = 4; rtw = 2; }      // same KHM, same LDS layout
+#endif
 #define V(NWV, R, C)                                                                   \
     if (nw == NWV && rtw == R && ct == C) {                                            \
         if (cx.imat_surf)                                                              \
@@ -475,6 +483,9 @@ int launch_sos_os(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t s
     }
     V(4, 1, 2) V(4, 2, 2) V(8, 2, 2)
     V(4, 1, 4) V(8, 1, 4)
+#ifdef SOS_WIDE_REGS
+    V(4, 2, 4)
+#endif
 #undef V
     return SOSGPU_E_UNSUPPORTED;
 }
