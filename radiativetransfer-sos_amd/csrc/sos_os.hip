@@ -35,9 +35,12 @@
 // ZO = true : output at an intermediate altitude (ZOUT != -1, SOS_OS.F:1511-1534) -- two extra levels per row are
 //             read back from the field after every formal solution.
 // Register bound: 256 architectural VGPRs (two workgroups per CU for NW = 4 when the LDS allows it).  The 512-register
-// form (accumulators and spills in AGPRs) of the CT = 4 variants was measured slower than the bounded form with a few
-// scratch spills (60.2k vs 63.6k bins/s at N = 41, NT = 60) and one instantiation gave wrong down-going rows on
-// gfx950, so it is not used.
+// form (256 VGPRs + 256 AGPRs, one workgroup per CU) of the 4-wave CT = 4 variants was measured slower in round 1 (60.2k vs
+// 63.6k bins/s at N = 41, NT = 60) and one instantiation gave wrong down-going rows then.  Re-examined in round 2 with
+// -DSOS_WIDE_REGS (below; builds <4,2,4,.> in that form and routes the <8,1,4> cases to it): all 85 parity and fuzz
+// tests pass, zout_n25_nt60 included (gpurun log wide_regs.log, profiles/r02_wide_regs.txt) -- the round-1 failure does not
+// reproduce on the current code (its write-back and ZOUT read-back were rewritten since), so there is no evidence of an
+// ordering bug hidden by register allocation in the shipped variants; the form stays unused because it is slower.
 #ifdef SOS_WIDE_REGS                                       // diagnostic build: 512-register form of the 4-wave CT = 4 variants
 #define SOS_MIN_WG(NW, CT) (((NW) == 4 && (CT) != 4) ? 2 : 1)
 #else
