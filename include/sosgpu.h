@@ -235,10 +235,12 @@ int  sosgpu_absprofile(int device, int nb, int nlev, int nterm, const int32_t *d
 
 /* Replaces SOS_MIE + SOS_FPHASE_MIE (src/SOS_MIE.F:205, :801) for a whole grid of size parameters, no MIE cache file:
  *   xmu[2 nbmu + 1]  cosines RMU(-nbmu:nbmu) of the Mie angle set (host); rn, in: refractive index (in <= 0)
- *   alphas[nalpha]   size parameters (host; the reference's grid: steps 1e-4 ... 1 growing with alpha, SOS_MIE.F:437-443)
+ *   alphas[nalpha]   size parameters, ascending (host; the reference's grid: steps 1e-4 ... 1 growing with alpha,
+ *                    SOS_MIE.F:437-443)
  *   d_rec[nalpha][4 + 3 (2 nbmu + 1)]  REAL*4 records {alpha, Qext, Qsca, 0, Imie(-nbmu:nbmu), Qmie(..), Umie(..)}
  *   d_g[nalpha]      asymmetry factor (double, as the file keeps it)
- * SOSGPU_E_UNSUPPORTED when 2 alpha + 24 coefficients do not fit LDS (alpha > ~840).  Synchronous. */
+ * The Mie coefficient arrays (2 alpha + 24 terms) live in LDS up to alpha = 850 and in a temporary HBM scratch beyond;
+ * SOSGPU_E_UNSUPPORTED past the reference's own dimension (CTE_MIE_DIM = 10000 terms, SOS.h:96).  Synchronous. */
 int  sosgpu_mie(int device, int nbmu, const double *xmu, double rn, double in, int nalpha, const double *alphas,
                 float *d_rec, double *d_g, void *stream);
 

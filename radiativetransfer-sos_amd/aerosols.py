@@ -1,17 +1,21 @@
 """Aerosol optical properties of one wavelength: what the reference's SOS_AEROSOLS writes to Aerosols.txt
-for the size-distribution models -- mono-modal log-normal / Junge (`-AER.Model 0`) and bimodal log-normal (`-AER.Model 3`).
+for every `-AER.Model`: 0 mono-modal log-normal / Junge, 1 WMO, 2 Shettle & Fenn, 3 bimodal log-normal, 4 external phase
+functions, 5 user mixture of log-normal / Junge modes.
 
     mie_angles        <- SOS_ANGLES for the Mie angle set  src/SOS_ANGLES.F:380-466 (Gauss nodes, D21.14 text values)
     alpha_grid        <- the size-parameter loop of SOS_MIE  src/SOS_MIE.F:434-443, 707-708
     mie_records       <- SOS_MIE + SOS_FPHASE_MIE on the GPU (csrc/mie.hip, C ABI sosgpu_mie), no MIE cache file
     granu             <- SOS_GRANU  src/SOS_AEROSOLS.F:4392-4820  size-distribution integral of the Mie records
     decompo_legendre  <- SOS_DECOMPO_LEGENDRE  src/SOS_AEROSOLS.F:3924-4390  truncation + Legendre expansions
-    aerosols          <- SOS_AEROSOLS  src/SOS_AEROSOLS.F:680 (IMOD = 0: :1150-1290; IMOD = 3: :1710-2125; closing :2771-2890)
+    init_param_wmo    <- SOS_INIT_PARAMWMO  src/SOS_AEROSOLS.F:3334   (component table $SOS_ABS_ROOT/fic/Data_WMO_*)
+    init_param_sf     <- SOS_INIT_PARAMSF   src/SOS_AEROSOLS.F:3557   (Data_SF_*, IRefrac_* tables)
+    aerosols          <- SOS_AEROSOLS  src/SOS_AEROSOLS.F:680 (IMOD = 0: :1150-1290; 1: :1312-1510; 2: :1517-1705;
+                         3: :1710-2125; 4: :2143-2280; 5: :2289-2770; closing :2771-2890)
 
-The other models (WMO, Shettle & Fenn, external phase functions, user mixtures) are not built; `-AER.UserFile` covers them.
 REAL*4 variables and literals of the Fortran are kept REAL*4 (`np.float32`) where they decide a value."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -227,6 +231,286 @@ def _round_index(rn, in_):
     return round(rn * 1000.) / 1000., -round(-in_ * 100000.) / 100000.
 
 
+def _lnd_component(xmu, rn, in_, rmodal, var, alphaf, wa, device):
+    rec = mie_records(xmu, rn, in_, MIE_ALPHAMIN, alphaf, device)
+    k1, k2, _, a11, a12, a33 = granu(rec, 1, rmodal, var, -999.0, wa)
+    return k1, k2, a11, a12, a33
+
+
+def _mix(components, xmu, wa, device):
+    """Number-weighted mixture of log-normal components [(weight, rn, in, rmodal, var, alphaf)] (SOS_AEROSOLS.F:1396-1493
+    for the WMO models, :1574-1686 for Shettle & Fenn): cross sections add, phase functions add weighted by the
+    scattering cross section and are normalised by the mixture's."""
+    w = len(xmu)
+    kmat1 = kmat2 = 0.
+    p11, p12, p33 = np.zeros(w), np.zeros(w), np.zeros(w)
+    for wt, rn, in_, rmodal, var, alphaf in components:
+        if wt == 0.:
+            continue
+        if MIE_ALPHAMIN > alphaf or alphaf >= 1e5:
+            raise AerosolError("size-parameter range of the Mie calculation is not valid (SOS_AEROSOLS ERROR_1009)")
+        k1, k2, a11, a12, a33 = _lnd_component(xmu, rn, in_, rmodal, var, alphaf, wa, device)
+        kmat1 = kmat1 + wt * k1
+        kmat2 = kmat2 + wt * k2
+        p11 = p11 + wt * a11 * k2
+        p12 = p12 + wt * a12 * k2
+        p33 = p33 + wt * a33 * k2
+    return kmat1, kmat2, p11 / kmat2, p12 / kmat2, p33 / kmat2
+
+
+def _fic(name):
+    root = os.environ.get("SOS_ABS_ROOT", "")
+    if not root:
+        raise AerosolError("SOS_ABS_ROOT is not defined (SOS_AEROSOLS ERROR_925)")
+    path = os.path.join(root, "fic", name)
+    if not os.path.exists(path):
+        raise AerosolError("aerosol data file %s not found" % path)
+    return path
+
+
+def _rows(path):
+    with open(path) as f:
+        return [[float(t) for t in ln.split()] for ln in f if ln.strip()]
+
+
+def _interpol(y1, y2, x1, x2, x):
+    return ((y2 - y1) / (x2 - x1)) * (x - x2) + y2          # SOS_INTERPOL, SOS_AEROSOLS.F:3844
+
+
+def _round_mr_mi(mr, mi):
+    # DNINT rounds half away from zero
+    return math.floor(mr * 1000. + 0.5) / 1000., -math.floor(-mi * 100000. + 0.5) / 100000.
+
+
+def init_param_wmo(wa):
+    """SOS_INIT_PARAMWMO (SOS_AEROSOLS.F:3334-3470): modal radii, ln-variances, volumes V and the refractive indices of the
+    four WMO components (dust-like, water-soluble, oceanic, soot) interpolated to wa.  A wavelength outside the table
+    leaves the indices at zero, like the reference's END= branch."""
+    rows = _rows(_fic("Data_WMO_cor_2015_12_16"))
+    r = rows[0][:4]
+    v2 = [x * math.log(10.) for x in rows[1][:4]]
+    vol = rows[2][:4]
+    mr, mi = [0.] * 4, [0.] * 4
+    tab = rows[3:]
+    for lo, hi in zip(tab[:-1], tab[1:]):
+        if lo[0] <= wa <= hi[0]:
+            for i in range(4):
+                a = _interpol(lo[1 + 2 * i], hi[1 + 2 * i], lo[0], hi[0], wa)
+                b = _interpol(lo[2 + 2 * i], hi[2 + 2 * i], lo[0], hi[0], wa)
+                mr[i], mi[i] = _round_mr_mi(a, b)
+            break
+    return r, v2, mr, mi, vol
+
+
+def _wmo_components(p, wa):
+    model = int(p["imodele_wmo"])
+    c = [0.] * 4
+    if model == 1:
+        c[0], c[1], c[3] = _F(0.70), _F(0.29), _F(0.01)
+    elif model == 2:
+        c[1], c[2] = _F(0.05), _F(0.95)
+    elif model == 3:
+        c[0], c[1], c[3] = _F(0.17), _F(0.61), _F(0.22)
+    elif model == 4:
+        c = [float(p["c_wmo_dl"]), float(p["c_wmo_ws"]), float(p["c_wmo_oc"]), float(p["c_wmo_so"])]
+    else:
+        raise AerosolError("-AER.WMO.Model must be 1..4")
+    r, v2, mr, mi, vol = init_param_wmo(wa)
+    n = [c[i] / vol[i] for i in range(4)]
+    ntot = 0.
+    for x in n:
+        ntot = ntot + x
+    alphaf = (4000., 50., 800., 10.)                        # CTE_ALPHAMAX_WMO_DL/WS/OC/SO, SOS.h:122-125
+    # the reference skips a component on C(I) = 0 (:1398)
+    return [((n[i] / ntot) if c[i] != 0. else 0., mr[i], mi[i], r[i], v2[i], alphaf[i]) for i in range(4)]
+
+
+def init_param_sf(wa, rh):
+    """SOS_INIT_PARAMSF (SOS_AEROSOLS.F:3557-3842): modal radii (interpolated in relative humidity), ln-variances and
+    refractive indices (interpolated in wavelength, then humidity) of the five Shettle & Fenn components
+    small rural, large rural, small urban, large urban, oceanic."""
+    rows = _rows(_fic("Data_SF_cor_2015_12_16"))
+    v2 = [x * math.log(10.) for x in rows[0][:5]]
+    r = [0.] * 5
+    tab = rows[1:]
+    rh1, rm1 = tab[0][0], tab[0][1:6]
+    rh2 = None
+    cpt = 1
+    if rh1 == rh:
+        r = list(rm1)
+    else:
+        for row in tab[1:]:
+            rh2, rm2 = row[0], row[1:6]
+            cpt += 1
+            if rh1 < rh <= rh2:
+                r = [_interpol(rm1[i], rm2[i], rh1, rh2, rh) for i in range(5)]
+                break
+            rh1, rm1 = rh2, rm2
+        else:
+            raise AerosolError("Error while reading the Shettle&Fenn component datafile (relative humidity outside the table)")
+    files = ("IRefrac_SR_cor_2015_12_16", "IRefrac_LR", "IRefrac_SU_cor_2015_12_16", "IRefrac_LU_cor_2015_12_16",
+             "IRefrac_OM_cor_2015_12_16")
+    mr, mi = [0.] * 5, [0.] * 5
+    for i, name in enumerate(files):
+        tabi = _rows(_fic(name))
+        found = False
+        for lo, hi in zip(tabi[:-1], tabi[1:]):
+            wa1, wa2 = lo[0], hi[0]
+            if wa1 <= wa <= wa2:
+                col = lambda row, h: (row[1 + 2 * (h - 1)], row[2 + 2 * (h - 1)])      # MR(h), MI(h), h = 1..8
+                if cpt == 1:
+                    a = _interpol(col(lo, cpt)[0], col(hi, cpt)[0], wa1, wa2, wa)
+                    b = _interpol(col(lo, cpt)[1], col(hi, cpt)[1], wa1, wa2, wa)
+                else:
+                    a1 = _interpol(col(lo, cpt - 1)[0], col(hi, cpt - 1)[0], wa1, wa2, wa)
+                    a2 = _interpol(col(lo, cpt)[0], col(hi, cpt)[0], wa1, wa2, wa)
+                    a = _interpol(a1, a2, rh1, rh2, rh)
+                    b1 = _interpol(col(lo, cpt - 1)[1], col(hi, cpt - 1)[1], wa1, wa2, wa)
+                    b2 = _interpol(col(lo, cpt)[1], col(hi, cpt)[1], wa1, wa2, wa)
+                    b = _interpol(b1, b2, rh1, rh2, rh)
+                mr[i], mi[i] = _round_mr_mi(a, b)
+                found = True
+                break
+        if not found:
+            break                                            # END=999: the remaining components keep zero indices
+    return r, v2, mr, mi
+
+
+def _sf_components(p, wa):
+    model = int(p["imodele_sf"])
+    ni = [0.] * 5
+    if model == 1:
+        ni[0] = 1.0
+    elif model == 2:
+        ni[2], ni[3] = _F(0.999875), _F(0.000125)
+    elif model == 3:
+        ni[0], ni[4] = _F(0.99), _F(0.01)
+    elif model == 4:
+        ni[0], ni[4] = _F(0.995), _F(0.005)
+    else:
+        raise AerosolError("-AER.SF.Model must be 1..4")
+    r, v2, mr, mi = init_param_sf(wa, float(p["rh"]))
+    out = []
+    for i in range(5):
+        if i == 0:
+            af = 70.                                        # CTE_ALPHAMAX_SF_SR
+        elif i == 2:
+            af = 90.                                        # CTE_ALPHAMAX_SF_SU
+        else:
+            af = float(np.float32(100 + 100 * math.trunc(2. * math.pi * _rmax_lnd(r[i], v2[i]) / (100. * wa)))) if ni[i] else 0.
+        out.append((ni[i], mr[i], mi[i], r[i], v2[i], af))
+    return out
+
+
+def _after_colon(line):
+    return line[line.index(":") + 1:].split()
+
+
+def _external_phase_functions(path, xmu):
+    """IMOD = 4 (SOS_AEROSOLS.F:2143-2280): extinction and scattering cross sections and F11, -F12/F11, F22/F11, F33/F11
+    versus scattering angle from the user's file; spline interpolation in cos(angle) to the Mie angle set."""
+    from .absorption import _spline, _splint
+    if not os.path.exists(path):
+        raise AerosolError("-AER.ExtData file %s not found" % path)
+    with open(path) as f:
+        lines = f.read().splitlines()
+    kmat1 = float(_after_colon(lines[0])[0].replace("D", "E").replace("d", "e"))
+    kmat2 = float(_after_colon(lines[1])[0].replace("D", "E").replace("d", "e"))
+    nang = int(_after_colon(lines[2])[0])
+    if nang > 200:
+        raise AerosolError("too many angles in the -AER.ExtData file (CTE_MAXNB_ANG_EXT = 200)")
+    rows = []
+    for ln in lines[4:4 + nang]:
+        t = [float(x.replace("D", "E").replace("d", "e")) for x in ln.replace(",", " ").split()[:5]]
+        if len(t) < 5:
+            raise AerosolError("error while reading the -AER.ExtData file")
+        rows.append(t)
+    if len(rows) < nang:
+        raise AerosolError("unexpected end of the -AER.ExtData file")
+    a = np.array(rows)
+    mu = np.cos(a[:, 0] * math.pi / 180.)
+    f11 = a[:, 1]
+    f12, f22, f33 = -a[:, 2] * f11, a[:, 3] * f11, a[:, 4] * f11
+    # SOS_INTERPO_SPLINT sorts the nodes by an exchange sort; equal abscissae do not occur for distinct angles
+    order = np.argsort(mu, kind="stable")
+    x = mu[order]
+    out = []
+    for y in (f11, f12, f22, f33):
+        ys = y[order]
+        dy1 = (ys[1] - ys[0]) / (x[1] - x[0])
+        dyn = (ys[-1] - ys[-2]) / (x[-1] - x[-2])
+        d2 = _spline(x, ys, dy1, dyn)
+        out.append(np.array([_splint(x, ys, d2, xv) for xv in xmu]))
+    p11, p12, p22, p33 = out
+    return kmat1, kmat2, p11, p12, p22, p33
+
+
+def read_mixture_file(path):
+    """The -AER.DefMixture file (SOS_AEROSOLS.F:2296-2372): number of modes, then per mode the size-distribution type and
+    parameters, the refractive indices at the simulation and reference wavelengths and the share of the reference AOT."""
+    if not os.path.exists(path):
+        raise AerosolError("-AER.DefMixture file %s not found" % path)
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines()]
+    it = iter(lines)
+    val = lambda: _after_colon(next(it))[0]
+    num = lambda: float(val().replace("D", "E").replace("d", "e"))
+    modes = []
+    for _ in range(int(val())):
+        kind = val().strip("'\"")
+        if kind == "LND":
+            r = num(); v = num()
+            m = dict(igranu=1, v1=r, v2=v, v3=-999.0)
+        elif kind == "JUNGE":
+            slope = num(); rmin = num(); rmax = num()
+            m = dict(igranu=2, v1=rmin, v2=slope, v3=rmax)
+        else:
+            raise AerosolError("mixture file: the size distribution must be LND or JUNGE")
+        m["rn_wa"], m["in_wa"], m["rn_waref"], m["in_waref"], m["rate"] = num(), num(), num(), num(), num()
+        modes.append(m)
+    return modes
+
+
+def _user_mixture(p, wa, xmu, device):
+    """IMOD = 5 (SOS_AEROSOLS.F:2289-2770): modes weighted so that each holds its share of the optical thickness at the
+    reference wavelength."""
+    modes = read_mixture_file(str(p["ficmixture_aer"]).strip())
+    if len(modes) > 20:
+        raise AerosolError("too many modes in the mixture file (CTE_MAX_NB_MODE_MIXTURE = 20)")
+    waref, ta_ref = float(p["waref_aot"]), float(p["aot_ref"])
+    aot = [ta_ref * m["rate"] for m in modes]
+    som = 0.
+    for m in modes:
+        som = som + m["rate"]
+    if abs(som - 1.) > 0.000001:                             # CTE_GAP_TOLER_SUM_RATES (double-precision context, SOS.h:184)
+        raise AerosolError("mixture file: the sum of the AOT rates is not equal to 1")
+    if som != 1.:
+        aot = [x / som for x in aot]
+    def alphaf_of(m):
+        rmax = _rmax_lnd(m["v1"], m["v2"]) if m["igranu"] == 1 else m["v3"]
+        return _alphaf(rmax, WAMIN)
+    coef, tot = [], 0.
+    for m, tau in zip(modes, aot):
+        rec = mie_records(xmu, m["rn_waref"], m["in_waref"], MIE_ALPHAMIN, alphaf_of(m), device)
+        k1 = granu(rec, m["igranu"], m["v1"], m["v2"], m["v3"], waref)[0]
+        coef.append(tau / k1)
+        tot = tot + coef[-1]
+    coef = [c / tot for c in coef]
+    w = len(xmu)
+    kmat1 = kmat2 = 0.
+    p11, p12, p33 = np.zeros(w), np.zeros(w), np.zeros(w)
+    for m, c in zip(modes, coef):
+        rn, in_ = (m["rn_waref"], m["in_waref"]) if wa == waref else (m["rn_wa"], m["in_wa"])
+        rec = mie_records(xmu, rn, in_, MIE_ALPHAMIN, alphaf_of(m), device)
+        k1, k2, _, a11, a12, a33 = granu(rec, m["igranu"], m["v1"], m["v2"], m["v3"], wa)
+        kmat1 = kmat1 + c * k1
+        kmat2 = kmat2 + c * k2
+        p11 = p11 + a11 * c * k2
+        p12 = p12 + a12 * c * k2
+        p33 = p33 + a33 * c * k2
+    return kmat1, kmat2, p11 / kmat2, p12 / kmat2, p33 / kmat2
+
+
 def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
     """SOS_AEROSOLS for the wavelength wa.  p: the sos_proc keyword dictionary (run_sos.SOS_PROC_KWARGS names); at_waref
     selects the refractive indices of the reference wavelength (the first of the two calls SOS_PROC makes when
@@ -235,6 +519,7 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
     imod = int(p["imod_aer"])
     itronc = int(p["itronc_aer"])
     xmu, xhr = mie_angles(nb_gauss_mie)
+    p22 = None
     sfx = "ref" if at_waref else ""
     if ta == 0.0:
         z = np.zeros(os_nb + 1)
@@ -289,10 +574,19 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
             p12 = p12 + c * a12 * k2
             p33 = p33 + c * a33 * k2
         p11, p12, p33 = p11 / kmat2, p12 / kmat2, p33 / kmat2
+    elif imod == 1:
+        kmat1, kmat2, p11, p12, p33 = _mix(_wmo_components(p, wa), xmu, wa, device)
+    elif imod == 2:
+        kmat1, kmat2, p11, p12, p33 = _mix(_sf_components(p, wa), xmu, wa, device)
+    elif imod == 4:
+        kmat1, kmat2, p11, p12, p22, p33 = _external_phase_functions(str(p["ficextdata_aer"]).strip(), xmu)
+    elif imod == 5:
+        kmat1, kmat2, p11, p12, p33 = _user_mixture(p, wa, xmu, device)
     else:
-        raise NotImplementedError("-AER.Model %d (WMO, Shettle & Fenn, external data, user mixtures) is not built; "
-                                  "give the phase-matrix expansion through -AER.UserFile" % imod)
-    d = decompo_legendre(itronc, xmu, xhr, os_nb, p11, p12, p11.copy(), p33)
+        raise AerosolError("-AER.Model must be 0..5")
+    if p22 is None:
+        p22 = p11.copy()                                # spherical particles (:1234, :1495, :1688, :2118, :2762)
+    d = decompo_legendre(itronc, xmu, xhr, os_nb, p11, p12, p22, p33)
     piz = kmat2 / kmat1
     ct = d["coef_tronca"]
     piztr = piz * (1. - ct / 2.) / (1. - piz * ct / 2.)

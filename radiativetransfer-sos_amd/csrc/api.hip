@@ -866,23 +866,33 @@ extern "C" int sosgpu_mie(int device, int nbmu, const double *xmu, double rn, do
     HIPCHK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     const int W = 2 * nbmu + 1;
-    double amax = 0.;
-    for (int i = 0; i < nalpha; i++) { if (!(alphas[i] > 0.)) return SOSGPU_E_ARG; amax = std::max(amax, alphas[i]); }
+    // ascending size parameters (SOS_MIE's grid): those whose 11 arrays of 2 alpha + 24 terms fit LDS form a prefix
+    const double lds_alpha = 850.;
+    double amax = 0., alds = 0.;
+    int n_lds = 0;
+    for (int i = 0; i < nalpha; i++) {
+        if (!(alphas[i] > 0.) || (i && alphas[i] < alphas[i - 1])) return SOSGPU_E_ARG;
+        amax = alphas[i];
+        if (alphas[i] <= lds_alpha) { n_lds = i + 1; alds = alphas[i]; }
+    }
+    if (2 * amax + 24 > 10000) return SOSGPU_E_UNSUPPORTED;                      // CTE_MIE_DIM, SOS.h:117
+    const size_t nscr = n_lds < nalpha ? mie_scratch_doubles(amax) : 0;
     char *buf = nullptr;
-    HIPCHK(hipMalloc((void **)&buf, (size_t)(W + nalpha) * sizeof(double) + 64));
-    double *d_xmu = (double *)buf, *d_al = d_xmu + W;
-    int32_t *d_err = (int32_t *)(d_al + nalpha);
+    HIPCHK(hipMalloc((void **)&buf, (size_t)(W + nalpha + nscr) * sizeof(double) + 64));
+    double *d_xmu = (double *)buf, *d_al = d_xmu + W, *d_scr = d_al + nalpha;
+    int32_t *d_err = (int32_t *)(d_scr + nscr);
     int32_t err = 0;
     hipError_t e = hipMemcpyAsync(d_xmu, xmu, W * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_al, alphas, nalpha * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, sizeof(int32_t), st);
     int rc = 0;
     if (e == hipSuccess) {
-        rc = launch_mie(nalpha, nbmu, d_xmu, rn, in, d_al, amax, d_rec, d_g, d_err, st);
+        rc = launch_mie(nalpha, nbmu, d_xmu, rn, in, d_al, n_lds, alds, amax, nscr ? d_scr : nullptr, d_rec, d_g, d_err, st);
         if (rc == 0) e = hipGetLastError();
     }
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(&err, d_err, sizeof err, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else (void)hipDeviceSynchronize();
     (void)hipFree(buf);
     if (rc == -3) return SOSGPU_E_UNSUPPORTED;
     if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }

@@ -13,9 +13,9 @@ Scope.  Supported: gas absorption by the CKD method (`-AP.
 `-AER.UserFile` (an Aerosols.txt) or by the extension keyword `aer_phase`, or none; exponential profiles
 (`-AP.AerProfile.Type 1`); surfaces `-SURF.Type` 0 (Lambert), 1 (+ Cox-Munk glitter), 2 (+ flat sea), 3 (Roujean),
 4 / 5 / 7 (Roujean + Rondeaux-Herman / Breon / Maignan); `-SOS.Trans`, `-SOS.Flux`, `SOS_Result.bin` files.
-Aerosol models `-AER.Model 0` (mono-modal log-normal / Junge) and 3 (bimodal log-normal): Mie theory on the GPU
-(aerosols.py, csrc/mie.hip).  Not built: the WMO / Shettle & Fenn / external-data / mixture models, the aerosol layer
-profile (`-AP.AerProfile.Type 2`, whose reference output depends on an unassigned variable), `-SURF.Type 6` (Nadal), which
+Every aerosol model of `-AER.Model`: 0 (mono-modal log-normal / Junge), 1 (WMO), 2 (Shettle & Fenn), 3 (bimodal
+log-normal), 4 (external phase functions), 5 (user mixture) -- Mie theory on the GPU (aerosols.py, csrc/mie.hip).
+Not built: the aerosol layer profile (`-AP.AerProfile.Type 2`, whose reference output depends on an unassigned variable), `-SURF.Type 6` (Nadal), which
 the reference's SOS_PROC refuses as well.
 
 Differences from the reference script that are deliberate: errors raise exceptions instead of being
@@ -393,9 +393,8 @@ def sos_proc(aer_phase=None, device=0, **kw):
         raise SosProcError("-AER.AOTref must be defined")
     user_aer = str(p["ficuser_aer"]).strip()
     use_model = p["aot_ref"] != 0.0 and aer_phase is None and user_aer == "NO_USER_AEROSOLS"
-    if use_model and p["imod_aer"] not in (0, 3):
-        raise NotImplementedError("-AER.Model %s (WMO, Shettle & Fenn, external data, user mixtures) is not built: give the "
-                                  "phase-matrix expansion through -AER.UserFile or aer_phase=" % p["imod_aer"])
+    if use_model and p["imod_aer"] not in (0, 1, 2, 3, 4, 5):
+        raise SosProcError("-AER.Model must be in 0..5")
     if p["hr"] == _D:
         raise SosProcError("-AP.HR must be defined")
     itrphi = p["itrphi"]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Trimmed copies of the reference's CKD data files for the wavelengths the tests use (authoring container only).
 
-tests/golden/fic/ mirrors $SOS_ABS_ROOT/fic: SO2-NO2 as it is, and for every gas the 50-interval coefficient file holding
+tests/golden/fic/ mirrors $SOS_ABS_ROOT/fic: SO2-NO2 and the aerosol component tables (Data_*, IRefrac_*) as they are, and for every gas the 50-interval coefficient file holding
 each test wavenumber with only THAT spectral interval's block kept -- every other interval is written as "no absorption"
 (NMAXAI = 0, which the file format provides for, SOS_SUB_TRS.F:745-757).  Header, temperature / pressure / mole-fraction
 grids and the kept blocks are copied byte for byte, so reading the kept interval gives exactly what the full file gives
@@ -54,6 +54,10 @@ if __name__ == "__main__":
     shutil.rmtree(DST, ignore_errors=True)
     os.makedirs(DST)
     shutil.copy(os.path.join(SRC, "SO2-NO2"), os.path.join(DST, "SO2-NO2"))
+    # component tables of the WMO and Shettle & Fenn aerosol models (7 small text files, as they are)
+    for name in sorted(os.listdir(SRC)):
+        if name.startswith("Data_") or name.startswith("IRefrac_"):
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     by_file = {}
     for nu in NUS:
         by_file.setdefault(A.ckd_file_name(1, nu, NUSTEP)[1], []).append(nu)

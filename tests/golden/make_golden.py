@@ -191,6 +191,69 @@ def gen_sos_proc_aer(only=None):
               "userfile", out2[-1], "i_up[0,:3]", out[5][0, :3])
 
 
+# Aerosol models beyond the log-normal ones: WMO, Shettle & Fenn, external phase functions, user mixtures.
+# "@GOLDEN/x" stands for the file x of this directory (resolved by the generator and by the tests).
+_MODBASE = {"-ANG.Rad.NbGauss": 24, "-ANG.Aer.NbGauss": 24, "-ANG.Thetas": 40.0, "-AP.Psurf": 1013.0, "-AP.HR": 8.0,
+            "-AP.AerHS.HA": 2.0, "-AP.AbsProfile.Type": 7, "-AER.AOTref": 0.25, "-AER.Waref": 0.550, "-AER.Tronca": 1,
+            "-SOS.IGmax": 100, "-SOS.View": 1, "-SOS.View.Phi": 60.0, "-SURF.Type": 0, "-SURF.Alb": 0.08}
+AER_MODEL_CASES = {
+    # WMO continental at the reference wavelength: dust-like component up to size parameter 4000
+    "wmo_continental": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-AER.Model": 1, "-AER.WMO.Model": 1}),
+    # WMO user mixture, simulation wavelength 0.865 != reference wavelength (two SOS_AEROSOLS calls, AOT rescaled)
+    "wmo_user_865": dict(_MODBASE, **{"-SOS_Main.Wa": 0.865, "-AER.Model": 1, "-AER.WMO.Model": 4, "-AER.WMO.DL": 0.2,
+                                      "-AER.WMO.WS": 0.5, "-AER.WMO.OC": 0.3, "-AER.WMO.SO": 0.0}),
+    # Shettle & Fenn maritime, relative humidity 70 % (interpolated indices), 0.67 um
+    "sf_maritime_rh70": dict(_MODBASE, **{"-SOS_Main.Wa": 0.670, "-AER.Model": 2, "-AER.SF.Model": 3, "-AER.SF.RH": 70.0}),
+    # Shettle & Fenn urban, dry (the RH = 0 branch), no truncation
+    "sf_urban_rh0": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-AER.Model": 2, "-AER.SF.Model": 2, "-AER.SF.RH": 0.0,
+                                      "-AER.Tronca": 0}),
+    # external phase functions (non-spherical: F22 != F11)
+    "ext_phase_fct": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-AER.Model": 4, "-AER.ExtData": "@GOLDEN/aer_ext_phase_fct.txt"}),
+    # user mixture LND + Junge + LND, 0.865 um
+    "mixture_3modes_865": dict(_MODBASE, **{"-SOS_Main.Wa": 0.865, "-AER.Model": 5, "-AER.DefMixture": "@GOLDEN/aer_mixture.txt"}),
+}
+
+
+def resolve_user(user):
+    return {k: (os.path.join(HERE, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v) for k, v in user.items()}
+
+
+def gen_aer_models(only=None):
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    import time
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    os.environ["SOS_ABS_ROOT"] = "/root/reference"
+    for name, user in AER_MODEL_CASES.items():
+        if only and name not in only:
+            continue
+        tmp = tempfile.mkdtemp(prefix="sosproc_")
+        t0 = time.time()
+        try:
+            u = resolve_user(user)
+            u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF",
+                      "-SOS_Main.Log": "NO_LOG_FILE", "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE",
+                      "-SOS.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+            p = rs.update_parameters(rs.default_parameters(), u)
+            out = R.sos_proc(list(rs.sos_proc_kwargs(p, trace=False).items()))
+            os_nb = 2 * int(user["-ANG.Aer.NbGauss"])
+            aer = rs.read_aerosols_file(os.path.join(tmp, "SOS", "Aerosols.txt"), os_nb)
+            head = open(os.path.join(tmp, "SOS", "Aerosols.txt")).read().splitlines()[:2]
+            kmat = [float(h.split(":")[1]) for h in head]
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        d = {"user_json": json.dumps(user), "kmat": np.array(kmat)}
+        for k, v in aer.items():
+            d["aer_" + k] = np.asarray(v)
+        for nm, v in zip(rs.OUTPUT_NAMES, out):
+            d[nm] = np.asarray(v)
+        np.savez_compressed(os.path.join(HERE, "aer_model_%s.npz" % name), **d)
+        print("aer_model", name, "%.0f s" % (time.time() - t0), "kmat", kmat, "a_tronc", aer["a_tronc"], "piztr", aer["piztr"],
+              "coef_tronca", out[-1], "i_up[0,:3]", out[5][0, :3])
+
+
 _CKDBASE = {"-ANG.Thetas": 35.0, "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0, "-AP.SpectralResol": 10.0, "-AP.Psurf": 1013.0,
             "-AER.Waref": 0.550, "-SOS.IGmax": 100, "-SOS.View": 1, "-SOS.View.Phi": 40.0}
 # Multi-bin CKD bands: the reference's own CKD tables under /root/reference/fic.
@@ -373,6 +436,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "aer_models":
+        gen_aer_models(sys.argv[2:])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proc_land":
         gen_sos_proc_land(sys.argv[2:])
         sys.exit(0)
@@ -390,6 +456,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_sos_proc()
     gen_sos_proc_aer()
+    gen_aer_models()
     gen_sos_proc_ckd()
     gen_absorption()
     gen_sos_proc_land()

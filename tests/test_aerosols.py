@@ -1,6 +1,7 @@
 """Aerosol models: Mie theory + size distribution + truncated Legendre expansion, against the Aerosols.txt
 content the compiled reference produced for the same parameters (the aer_* arrays of tests/golden/sos_proc_*.npz, captured by
-make_golden.py proc_aer / proc_land / proc_ckd) -- mono-modal LND (configs 2, 3, 5), bimodal LND (config 4).
+make_golden.py proc_aer / proc_land / proc_ckd / aer_models) -- mono-modal LND (configs 2, 3, 5), bimodal LND (config 4),
+WMO, Shettle & Fenn, external phase functions, user mixtures.
 The reference itself passes the Mie results through a REAL*4 file, so agreement is at the REAL*4 level: coefficients to 2e-6 of
 beta_0 = 1; the printed truncation coefficient and albedo (F9.5) exactly or within their last digit."""
 import json
@@ -54,6 +55,55 @@ def test_aerosol_model_vs_reference_aerosols_file(gpu_pkg, name):
     assert np.allclose([got["kmat1"], got["kmat2"]], g["kmat"], rtol=6e-5)          # printed E13.5: five digits
     if "coef_tronca" in g.files and float(g["coef_tronca"]) != 0.0:
         assert abs(got["coef_tronca"] - float(g["coef_tronca"])) <= 2e-6
+
+
+MODEL_CASES = ["wmo_continental", "wmo_user_865", "sf_maritime_rh70", "sf_urban_rh0", "ext_phase_fct", "mixture_3modes_865"]
+
+
+def _resolve(user):
+    return {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v) for k, v in user.items()}
+
+
+def test_component_tables_of_the_wmo_and_sf_models(pkg, monkeypatch):
+    """SOS_INIT_PARAMWMO / SOS_INIT_PARAMSF on the reference's tables: hand-checked rows (0.55 um lies between the 0.5 and
+    0.55 rows; relative humidity 70 % is a table row, so the modal radii are that row's)."""
+    monkeypatch.setenv("SOS_ABS_ROOT", GOLD)
+    A = pkg.aerosols
+    r, v2, mr, mi, vol = A.init_param_wmo(0.55)
+    assert r == [0.5, 0.005, 0.3, 0.0118] and abs(v2[3] - 0.30103 * np.log(10.)) < 1e-15 and vol[1] == 113.98352e-6
+    assert mr == [1.53, 1.53, 1.381, 1.75] and mi[:2] == [-0.008, -0.006] and mi[3] == -0.44
+    r, v2, mr, mi = A.init_param_sf(0.55, 70.0)
+    assert r == [0.02846, 0.4571, 0.02911, 0.4777, 0.2041] and abs(v2[0] - 0.35 * np.log(10.)) < 1e-15
+    r0, _, mr0, _ = A.init_param_sf(0.55, 0.0)
+    assert r0 == [0.027, 0.43, 0.025, 0.4, 0.16] and mr0[0] == 1.53
+    with pytest.raises(A.AerosolError):
+        A.init_param_sf(0.55, 99.5)                          # beyond the last humidity row: the reference fails on the read
+    modes = A.read_mixture_file(os.path.join(GOLD, "aer_mixture.txt"))
+    assert [m["igranu"] for m in modes] == [1, 2, 1] and modes[1]["v3"] == 12.0 and abs(sum(m["rate"] for m in modes) - 1) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_other_aerosol_models_vs_reference(gpu_pkg, name, monkeypatch):
+    """-AER.Model 1 (WMO), 2 (Shettle & Fenn), 4 (external phase functions), 5 (user mixture) against the Aerosols.txt
+    and the radiances of the compiled reference (tests/golden/aer_model_*.npz, make_golden.py aer_models).  The WMO
+    dust-like component runs Mie theory up to size parameter 4000 (HBM-scratch form of k_mie)."""
+    import cases
+    monkeypatch.setenv("SOS_ABS_ROOT", GOLD)
+    rs, A = gpu_pkg.run_sos, gpu_pkg.aerosols
+    g = np.load(os.path.join(GOLD, "aer_model_%s.npz" % name))
+    user = _resolve(json.loads(str(g["user_json"])))
+    p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
+    nb_mie = int(user["-ANG.Aer.NbGauss"])
+    got = A.aerosols(p, user["-SOS_Main.Wa"], 0.1, nb_mie, 2 * nb_mie, at_waref=user["-SOS_Main.Wa"] == user["-AER.Waref"])
+    for k in ("alpha", "beta", "gamma", "zeta"):
+        ref = g["aer_" + k]
+        assert np.abs(got[k] - ref).max() <= 3e-6, (k, np.abs(got[k] - ref).max())
+    assert abs(got["a_tronc"] - float(g["aer_a_tronc"])) <= 1.001e-5 and abs(got["piztr"] - float(g["aer_piztr"])) <= 1.001e-5
+    assert np.allclose([got["kmat1"], got["kmat2"]], g["kmat"], rtol=6e-5)
+    user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+    out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
+    cases.compare_proc_outputs(rs, out, g, rtol=2e-5)
 
 
 @pytest.mark.gpu
