@@ -59,7 +59,7 @@ def test_sos_proc_rejects_bad_or_unsupported_parameters(pkg):
         rs.sos_proc(**kw(**{"-AP.AbsProfile.Type": 2, "-AP.Psurf": 1013.0}))
     with pytest.raises(rs.SosProcError):
         rs.sos_proc(**kw(**{"-AP.AbsProfile.Type": 9}))
-    with pytest.raises(NotImplementedError):                   # aerosol models without a phase-matrix file
+    with pytest.raises(rs.SosProcError):                       # aerosols asked for, -AER.Model left undefined
         rs.sos_proc(**kw(**{"-AER.AOTref": 0.3}))
     with pytest.raises(NotImplementedError):                   # aerosol layer profile (reference output not reproducible)
         rs.sos_proc(**kw(**{"-AP.AerProfile.Type": 2}))
