@@ -375,9 +375,10 @@ def sos_proc(kwargs_in_order):
     return (lum_nbmu.value, ind_angout, phi, theta, *[np.ascontiguousarray(t) for t in tabs], *[s.value for s in scal])
 
 
-def sos_profile(tr, hr, ta, ha, altabs=None, tabs=None, absprofil=1):
-    """Reference SOS_PROFILE (SOS_PROFIL.F:224) for IPROFIL=1; the PROFIL file it writes is parsed with the read format of
-    SOS.F:515,692 (`2X,I5,F10.5,3(E15.8)`).  Same return as oracle_ctypes.sos_profile."""
+def sos_profile(tr, hr, ta, ha, altabs=None, tabs=None, absprofil=1, iprofil=1, zmin=0.0, zmax=0.0):
+    """Reference SOS_PROFILE (SOS_PROFIL.F:224); the PROFIL file it writes is parsed with the read format of
+    SOS.F:515,692 (`2X,I5,F10.5,3(E15.8)`).  Same return as oracle_ctypes.sos_profile.  iprofil = 2 (aerosol layer between
+    zmin and zmax): that branch reads a local Hmol(0) before assigning it, so call it first thing in a fresh process."""
     tmp = tempfile.mkdtemp(prefix="sosref_")
     try:
         fic = os.path.join(tmp, "PROFIL")
@@ -389,7 +390,7 @@ def sos_profile(tr, hr, ta, ha, altabs=None, tabs=None, absprofil=1):
         d = lambda v: C.byref(C.c_double(v))
 
         def call():
-            lib().sos_profile_(C.byref(C.c_int16(1)), d(tr), d(hr), d(ta), d(ha), d(0.0), d(0.0),
+            lib().sos_profile_(C.byref(C.c_int16(iprofil)), d(tr), d(hr), d(ta), d(ha), d(zmin), d(zmax),
                                C.byref(C.c_int16(absprofil)), _p(a_alt), _p(a_tab), C.byref(C.c_int32(0)),
                                C.byref(C.c_int32(99)), _fstr(fic), C.byref(nt), C.byref(ier), C.c_size_t(LENFIC2))
 

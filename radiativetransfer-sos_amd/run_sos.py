@@ -15,8 +15,9 @@ Scope.  Supported: gas absorption by the CKD method (`-AP.
 4 / 5 / 7 (Roujean + Rondeaux-Herman / Breon / Maignan); `-SOS.Trans`, `-SOS.Flux`, `SOS_Result.bin` files.
 Every aerosol model of `-AER.Model`: 0 (mono-modal log-normal / Junge), 1 (WMO), 2 (Shettle & Fenn), 3 (bimodal
 log-normal), 4 (external phase functions), 5 (user mixture) -- Mie theory on the GPU (aerosols.py, csrc/mie.hip).
-Not built: the aerosol layer profile (`-AP.AerProfile.Type 2`, whose reference output depends on an unassigned variable), `-SURF.Type 6` (Nadal), which
-the reference's SOS_PROC refuses as well.
+Both aerosol profiles: exponential (`-AP.AerProfile.Type 1`) and a layer between two altitudes (2; the reference reads an
+unassigned Hmol(0) there -- see profile_layer).  Not built: `-SURF.Type 6` (Nadal), which the reference's SOS_PROC refuses
+as well.
 
 Differences from the reference script that are deliberate: errors raise exceptions instead of being
 lost in an `intent(in)` `ier`; `gen_sos_output` imports `ceil` and uses `and` (the reference has `1 & updown == 2`);
@@ -329,6 +330,71 @@ def profile_nogas(tr, hr, ta, ha):
     return _round_sig(h, 8), _round_sig(pcaer, 8), _round_sig(pcmol, 8), np.round(z, 5)
 
 
+def profile_layer(tr, hr, ta, zmin, zmax):
+    """SOS_PROFILE for IPROFIL=2 (SOS_PROFIL.F:800-946): a homogeneous aerosol + molecule layer between zmin and zmax (km)
+    inside a molecular atmosphere, no gas absorption, then the PROFIL_TMP text round trip.  Returns h, xdel, ydel, zprof.
+
+    The reference starts its recurrence `Hmol(I)=Hmol(I-1)+VR_SC` (:873) from an Hmol(0) it assigns only at :926 -- a local
+    array element read before it is written.  On a fresh stack it is 0, which is also the evident intent (the optical
+    depth at the top of the atmosphere, assigned TR*exp(-120/HR) ~ 1e-7 TR afterwards); this restatement starts from 0 and
+    is pinned against the reference's routine called on a fresh stack (tests/golden/profile_layer.npz)."""
+    if zmin < 0.0 or zmax <= zmin:
+        raise SosProcError("SOS_PROFIL: -AP.AerLayer.Zmin / Zmax must satisfy 0 <= Zmin < Zmax", ier=-1)
+    ttot = tr + ta
+    nt = int(ttot / CTE_TCOUCHE)
+    if nt > CTE_OS_NT:
+        nt = CTE_OS_NT
+    dzt = _F(0.010)                                   # CTE_DZTRANSI (REAL*4 literal, SOS.h:240)
+    vr_c1 = tr * math.exp(-(zmax + dzt) / hr)
+    vr_c2 = tr * (math.exp(-zmin / hr) - math.exp(-(zmax + dzt) / hr))
+    if zmin == 0.0:
+        vr_c3, nb_tr = 0.0, 1
+    else:
+        vr_c3, nb_tr = tr * (1.0 - math.exp(-(zmin - dzt) / hr)), 2
+    nbsc_c1 = max(3, int((nt - nb_tr) * vr_c1 / (tr + ta)))              # CTE_PROFIL_MIN_NBC = 3
+    nbsc_c3 = 0 if zmin == 0.0 else max(3, int((nt - nb_tr) * vr_c3 / (tr + ta)))
+    nbsc_c2 = (nt - nb_tr) - nbsc_c1 - nbsc_c3
+    if nbsc_c2 <= 0 or (ta / nbsc_c2) < _F(0.00001):
+        raise SosProcError("SOS_PROFIL: not enough sublayers in the aerosol layer (ERROR 1020)", ier=-1)
+    hmol = np.zeros(nt + 1); haer = np.zeros(nt + 1)
+    vr_sc = vr_c1 / nbsc_c1
+    for i in range(1, nbsc_c1 + 1):
+        hmol[i] = hmol[i - 1] + vr_sc
+    i = nbsc_c1 + 1
+    hmol[i] = tr * math.exp(-zmax / hr)
+    vr_sc = hmol[i] - hmol[i - 1]
+    haer[i] = haer[i - 1] + (ta * vr_sc / vr_c2)
+    delta_z = (zmax - zmin) / nbsc_c2
+    z = zmax
+    for i in range(nbsc_c1 + 2, nbsc_c1 + nbsc_c2 + 2):
+        z = z - delta_z
+        hmol[i] = tr * math.exp(-z / hr)
+        vr_sc = hmol[i] - hmol[i - 1]
+        haer[i] = haer[i - 1] + (ta * vr_sc / vr_c2)
+    if zmin != 0.0:
+        i = nbsc_c1 + nbsc_c2 + 2
+        hmol[i] = tr * math.exp(-(zmin - dzt) / hr)
+        haer[i] = haer[i - 1]
+        vr_sc = vr_c3 / nbsc_c3
+        for i in range(nbsc_c1 + nbsc_c2 + 3, nt + 1):
+            hmol[i] = vr_sc + hmol[i - 1]
+            haer[i] = haer[i - 1]
+    zprof = np.zeros(nt + 1); h = np.zeros(nt + 1); pcaer = np.zeros(nt + 1); pcmol = np.zeros(nt + 1)
+    zprof[0] = CTE_TOA_ALT
+    hmol[0] = tr * math.exp(-CTE_TOA_ALT / hr)
+    h[0] = hmol[0] + haer[0]
+    pcmol[0] = 1.0
+    for i in range(1, nt + 1):
+        h[i] = hmol[i] + haer[i]
+        zprof[i] = hr * math.log(tr / hmol[i])
+        if haer[i] == haer[i - 1]:
+            pcaer[i], pcmol[i] = 0.0, 1.0
+        else:
+            pcmol[i] = 1 / (1 + (ta / vr_c2))
+            pcaer[i] = 1 - pcmol[i]
+    return _round_sig(h, 8), _round_sig(pcaer, 8), _round_sig(pcmol, 8), np.round(zprof, 5)
+
+
 def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, land=None):
     """SOS_TRPHI_OPTION (SOS_TRPHI.F:431-615): run the azimuth recomposition on the GPU for the azimuth list of
     the view mode and pack the fourteen (361,81) tables plus PHI_FIN(361), THETA_FIN(81)."""
@@ -380,8 +446,11 @@ def sos_proc(aer_phase=None, device=0, **kw):
         raise SosProcError("-SOS_Main.Wa must be defined")
     if p["tetas"] == _D or not (0.0 <= p["tetas"] < 90.0):
         raise SosProcError("-ANG.Thetas must be defined in [0,90[")
-    if p["iprofil"] != 1:
-        raise NotImplementedError("-AP.AerProfile.Type 2 (layer between Zmin/Zmax) is not in this round's scope")
+    iprofil = int(p["iprofil"])
+    if iprofil not in (1, 2):                                                      # SOS_PROC.F:2324-2325
+        raise SosProcError("-AP.AerProfile.Type must be 1 or 2")
+    if iprofil == 2 and (p["zmin"] == _D or p["zmax"] == _D):                      # :2335-2338
+        raise SosProcError("-AP.AerLayer.Zmin and -AP.AerLayer.Zmax must be defined for -AP.AerProfile.Type 2")
     absprofil = int(p["absprofil"])
     if absprofil == _I or not 0 <= absprofil <= 7:
         raise SosProcError("-AP.AbsProfile.Type must be defined in 0..7")
@@ -451,7 +520,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
         if len(beta) != os_nb + 1:
             raise SosProcError("aer_phase arrays must have OS_NB+1 = %d entries" % (os_nb + 1))
         piz, piztr, a_tronc = float(aer_phase["piz"]), float(aer_phase["piztr"]), float(aer_phase.get("a_tronc", 0.0))
-        if p["ha"] == _D:
+        if iprofil == 1 and p["ha"] == _D:
             raise SosProcError("-AP.AerHS.HA must be defined")
 
     # --- molecular optical thickness (SOS_PROC.F:3331-3351)
@@ -465,6 +534,8 @@ def sos_proc(aer_phase=None, device=0, **kw):
 
     # --- gas absorption: SOS_PREPA_ABSPROFILE + the weights of the CKD bins (SOS_PROC.F:3359-3416)
     use_gas = absprofil != 7
+    if iprofil == 2 and use_gas:                                                   # SOS_PROC.F:2352
+        raise SosProcError("-AP.AerProfile.Type 2 requires -AP.AbsProfile.Type 7 (no gas absorption)")
     if use_gas:
         if p["nustep"] == _I:
             raise SosProcError("-AP.SpectralResol must be defined with -AP.AbsProfile.Type != 7")
@@ -517,7 +588,10 @@ def sos_proc(aer_phase=None, device=0, **kw):
     try:
         # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device, one fused solve, one aggregate
         if not use_gas:
-            h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, ha)
+            if iprofil == 1:
+                h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, ha)
+            else:
+                h, xdel, ydel, zprof = profile_layer(tr, p["hr"], ta, float(p["zmin"]), float(p["zmax"]))
             ttot_vrai = h[-1]
             h, xdel, ydel, ib = rescale_profile(h, xdel, ydel, a_tronc, piz, piztr, os_nb)   # SOS.F:523-550
             bins = ctx.upload_bins(h[None], xdel[None], ydel[None], iborm=np.array([min(ib, iborm)], dtype=np.int32),

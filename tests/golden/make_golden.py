@@ -147,6 +147,12 @@ PROC_AER_CASES = {
     # flat sea + LND aerosol, output at 2 km
     "flatsea_lnd": dict(_AERBASE, **_LND, **{"-SOS.View": 1, "-SOS.View.Phi": 0.0, "-SURF.Type": 2, "-SURF.Alb": 0.02,
                                              "-SURF.Ind": 1.34, "-SOS.OutputAlt": 2.0, "-ANG.Rad.NbGauss": 24}),
+    # aerosol layer between 1 and 3 km (-AP.AerProfile.Type 2), LND aerosol, Lambert, output at 2 km (inside the layer).
+    # Generate it ALONE in a fresh process (python make_golden.py proc_aer layer_1_3km_lnd): SOS_PROFILE reads a local
+    # Hmol(0) before assigning it in that branch.
+    "layer_1_3km_lnd": dict(_AERBASE, **_LND, **{"-SOS.View": 1, "-SOS.View.Phi": 90.0, "-SURF.Type": 0, "-SURF.Alb": 0.15,
+                                                 "-AP.AerProfile.Type": 2, "-AP.AerLayer.Zmin": 1.0, "-AP.AerLayer.Zmax": 3.0,
+                                                 "-SOS.OutputAlt": 2.0, "-ANG.Rad.NbGauss": 24}),
 }
 
 
@@ -177,7 +183,12 @@ def gen_sos_proc_aer(only=None):
             u2 = dict(u, **{"-AER.UserFile": os.path.join(tmp, "SOS", "Aerosols.txt"), "-SOS_Main.ResRoot": tmp + "/B"})
             p2 = rs.update_parameters(rs.default_parameters(), u2)
             out2 = R.sos_proc(list(rs.sos_proc_kwargs(p2, trace=False).items()))
-            assert np.array_equal(out[5], out2[5]) and np.array_equal(out[6], out2[6]), "user-file rerun differs"
+            same = np.array_equal(out[5], out2[5]) and np.array_equal(out[6], out2[6])
+            if user.get("-AP.AerProfile.Type", 1) == 2:
+                # second SOS_PROFILE call of the process: Hmol(0) holds the first call's value (see profile_layer)
+                print("   layer profile, rerun max rel diff", np.abs(out2[5] - out[5]).max() / np.abs(out[5]).max())
+            else:
+                assert same, "user-file rerun differs"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
         d = {"user_json": json.dumps(user), "result_bin": np.array(recs), "ig_counts": np.array(ig, dtype=np.int32),
@@ -399,6 +410,32 @@ def gen_sos_proc_land(only=None):
               "i_up[0,:3]", out[5][0, :3])
 
 
+LAYER_CASES = [(0.0948, 8.0, 0.3, 1.0, 3.0), (0.0948, 8.0, 0.3, 0.0, 2.0), (0.05, 8.0, 0.8, 2.0, 4.5), (0.2, 8.0, 0.1, 0.5, 1.0),
+               (0.0233, 8.0, 1.5, 0.0, 0.8)]
+
+
+def gen_profile_layer(index=None):
+    """SOS_PROFILE with IPROFIL = 2.  Each case runs as the FIRST call of a fresh process (the branch reads the local
+    Hmol(0) before assigning it; on a fresh stack it is 0): the parent collects the children's outputs."""
+    import json
+    import subprocess
+    if index is not None:
+        tr, hr, ta, zmin, zmax = LAYER_CASES[int(index)]
+        r = R.sos_profile(tr, hr, ta, 2.0, absprofil=7, iprofil=2, zmin=zmin, zmax=zmax)
+        print("LAYER_JSON " + json.dumps({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items()}))
+        return
+    d = {"cases": np.array(LAYER_CASES)}
+    for i in range(len(LAYER_CASES)):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "profile_layer", str(i)], capture_output=True, text=True,
+                             check=True).stdout
+        r = json.loads([ln for ln in out.splitlines() if ln.startswith("LAYER_JSON ")][0][11:])
+        assert r["ier"] == 0
+        for k in ("zprof", "h", "xdel", "ydel"):
+            d["%s_%d" % (k, i)] = np.array(r[k])
+        print("profile_layer", i, LAYER_CASES[i], "nt", r["nt"])
+    np.savez_compressed(os.path.join(HERE, "profile_layer.npz"), **d)
+
+
 def gen_aggregate():
     """SOS_AGGREGATE called once per bin in bin order (the reference appends one all-zero record per call after the
     first; those trailing records are part of the fixture)."""
@@ -436,6 +473,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "profile_layer":
+        gen_profile_layer(sys.argv[2] if len(sys.argv) > 2 else None)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "aer_models":
         gen_aer_models(sys.argv[2:])
         sys.exit(0)
@@ -457,6 +497,7 @@ if __name__ == "__main__":
     gen_sos_proc()
     gen_sos_proc_aer()
     gen_aer_models()
+    gen_profile_layer()
     gen_sos_proc_ckd()
     gen_absorption()
     gen_sos_proc_land()

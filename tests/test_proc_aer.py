@@ -15,7 +15,7 @@ import pytest
 import cases
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-AER_CASES = ["cfg2_lnd_lambert", "cfg4_glitter_bilnd", "flatsea_lnd"]
+AER_CASES = ["cfg2_lnd_lambert", "cfg4_glitter_bilnd", "flatsea_lnd", "layer_1_3km_lnd"]
 
 
 def _aer(g):
@@ -28,7 +28,11 @@ def _setup(rs, S, user, aer):
     os_nb, os_ns = 2 * nb_mie, 2 * nb_lum
     mu, ga, n0, _ = rs.angles(nb_lum, user["-ANG.Thetas"])
     tr = rs.rayleigh_optical_thickness(user["-SOS_Main.Wa"], user["-AP.Psurf"])
-    h, xdel, ydel, zprof = rs.profile_nogas(tr, user["-AP.HR"], user["-AER.AOTref"], user["-AP.AerHS.HA"])
+    if user.get("-AP.AerProfile.Type", 1) == 2:
+        h, xdel, ydel, zprof = rs.profile_layer(tr, user["-AP.HR"], user["-AER.AOTref"], user["-AP.AerLayer.Zmin"],
+                                                user["-AP.AerLayer.Zmax"])
+    else:
+        h, xdel, ydel, zprof = rs.profile_nogas(tr, user["-AP.HR"], user["-AER.AOTref"], user["-AP.AerHS.HA"])
     h2, x2, y2, iborm = S.rescale_profile(h, xdel, ydel, float(aer["a_tronc"]), float(aer["piz"]), float(aer["piztr"]), os_nb)
     return dict(mu=mu, ga=ga, n0=n0, os_nb=os_nb, os_ns=os_ns, os_nm=os_nb + os_ns, h=h2, xdel=x2, ydel=y2, zprof=zprof,
                 iborm=iborm, ttot_vrai=h[-1])

@@ -213,3 +213,23 @@ def test_device_profile_random_columns(gpu_pkg, oracle):
         exact += int(all(np.array_equal(prof[b, row, :k], r[key]) for row, key in enumerate(("h", "xdel", "ydel"))))
     print("bit-identical bins: %d/%d" % (exact, nb))
     cx.close()
+
+
+def test_layer_profile_vs_reference(pkg):
+    """-AP.AerProfile.Type 2 (aerosol layer between two altitudes, SOS_PROFIL.F:800-946): run_sos.profile_layer equals the
+    PROFIL file of the reference's SOS_PROFILE, each golden case being the first call of a fresh process (that branch reads
+    the local Hmol(0) before assigning it; on a fresh stack it is 0 -- tests/golden/make_golden.py profile_layer).
+    Levels, altitudes (F10.5) and the three E15.8 columns are identical; Zmin = 0 (no third layer) included."""
+    rs = pkg.run_sos
+    g = np.load(os.path.join(os.path.dirname(GOLD), "profile_layer.npz"))
+    for i, (tr, hr, ta, zmin, zmax) in enumerate(g["cases"]):
+        h, xdel, ydel, z = rs.profile_layer(tr, hr, ta, zmin, zmax)
+        assert len(h) == len(g["h_%d" % i])
+        assert np.array_equal(h, g["h_%d" % i]) and np.array_equal(z, g["zprof_%d" % i]), i
+        assert np.array_equal(xdel, g["xdel_%d" % i]) and np.array_equal(ydel, g["ydel_%d" % i]), i
+        inside = (z[1:] < zmax + 1e-9) & (z[1:] > zmin - 1e-9)
+        assert np.all(xdel[1:][~inside & (z[1:] > zmax + 0.011)] == 0.0) and xdel[1:][inside].min() > 0.0
+    with pytest.raises(rs.SosProcError):
+        rs.profile_layer(0.1, 8.0, 0.3, 2.0, 1.0)            # Zmax <= Zmin: the reference's error 1010
+    with pytest.raises(rs.SosProcError):
+        rs.profile_layer(0.1, 8.0, 2e-5, 1.0, 3.0)           # less than 1e-5 of aerosol per sublayer: error 1020

@@ -61,8 +61,11 @@ def test_sos_proc_rejects_bad_or_unsupported_parameters(pkg):
         rs.sos_proc(**kw(**{"-AP.AbsProfile.Type": 9}))
     with pytest.raises(rs.SosProcError):                       # aerosols asked for, -AER.Model left undefined
         rs.sos_proc(**kw(**{"-AER.AOTref": 0.3}))
-    with pytest.raises(NotImplementedError):                   # aerosol layer profile (reference output not reproducible)
+    with pytest.raises(rs.SosProcError):                       # aerosol layer profile without its two altitudes
         rs.sos_proc(**kw(**{"-AP.AerProfile.Type": 2}))
+    with pytest.raises(rs.SosProcError):                       # ... and it excludes gas absorption (SOS_PROC.F:2352)
+        rs.sos_proc(**kw(**{"-AP.AerProfile.Type": 2, "-AP.AerLayer.Zmin": 1.0, "-AP.AerLayer.Zmax": 2.0,
+                            "-AP.AbsProfile.Type": 2, "-AP.Psurf": 1013.0, "-AP.SpectralResol": 10}))
     with pytest.raises(TypeError):
         rs.sos_proc(wa_simu=0.55)
 
