@@ -425,6 +425,183 @@ def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, 
     return phi_fin, theta_fin, tabs, tabs_dn
 
 
+def validate_parameters(p):
+    """The user-parameter checks of SOS_PROC in the reference's order (SOS_PROC.F:1310-1335, 1540-2475): the first violated
+    rule raises SosProcError carrying the reference's error number (`.code`, the label of its message block at
+    SOS_PROC.F:4074-4745) and the keyword to fix.  Side effects of that block are mirrored too: with a single wavelength
+    the reference-wavelength refractive indices default to the simulation ones (:1704-1707, :1812-1818)."""
+    def fail(code, text):
+        e = SosProcError("SOS_PROC : ERROR_%s on parameters -- %s" % (code, text))
+        e.code = code
+        raise e
+    und = lambda k: p[k] == _D                       # CTE_NOT_DEFINED_VALUE_DBLE = -999. and _INT = -999 compare equal
+    user_aer = str(p["ficuser_aer"]).strip() != "NO_USER_AEROSOLS"
+    # (ERROR_1000, -SOS_Main.ResRoot undefined, is not mirrored: without a results directory this implementation simply
+    #  writes no files -- a deliberate difference, see the module docstring)
+    if und("aot_ref"):
+        fail(2301, "-AER.AOTref (aerosol optical thickness at the reference wavelength) must be defined")
+    if p["aot_ref"] > 0.0:
+        if und("imod_aer") and not user_aer:
+            fail(2304, "-AER.Model must be defined (0 mono-modal, 1 WMO, 2 Shettle & Fenn, 3 bimodal log-normal, "
+                       "4 external phase functions, 5 user mixture)")
+        if und("waref_aot"):
+            fail(2302, "-AER.Waref (reference wavelength of the aerosol optical thickness) must be defined")
+    if und("wa_simu"):
+        fail(2100, "-SOS_Main.Wa (simulation wavelength, microns) must be defined")
+    if p["wa_simu"] < _F(0.364) or p["wa_simu"] > _F(4.0):                          # CTE_WAMIN, CTE_WAMAX (SOS.h:70-71)
+        fail(2101, "-SOS_Main.Wa = %r outside [0.364, 4.0] microns" % p["wa_simu"])
+    if und("tetas"):
+        fail(2200, "-ANG.Thetas (solar zenith angle, degrees) must be defined")
+    if p["tetas"] < 0.0 or p["tetas"] >= 90.0:
+        fail(2201, "-ANG.Thetas out of [0, 90[")
+    if p["aot_ref"] > 0.0 and not user_aer:
+        imod = int(p["imod_aer"])
+        one_wl = p["wa_simu"] == p["waref_aot"]
+        if imod < 0 or imod > 5:
+            fail(2305, "-AER.Model out of 0..5")
+        if int(p["itronc_aer"]) not in (0, 1):
+            fail(23141, "-AER.Tronca must be 0 or 1")
+        if imod == 0:
+            if und("rn_wa") or und("in_wa"):
+                fail(2309, "-AER.MMD.MRwa and -AER.MMD.MIwa must be defined")
+            if p["in_wa"] > 0.0:
+                fail(2310, "-AER.MMD.MIwa must be negative or null")
+            if und("igranu"):
+                fail(2311, "-AER.MMD.SDtype must be defined (1 log-normal, 2 Junge)")
+            if int(p["igranu"]) not in (1, 2):
+                fail(2312, "-AER.MMD.SDtype must be 1 or 2")
+            if int(p["igranu"]) == 1 and (und("lnd_radius_mmd_aer") or und("lnd_lnvar_mmd_aer")):
+                fail(23131, "-AER.MMD.LNDradius and -AER.MMD.LNDvar must be defined")
+            if int(p["igranu"]) == 2 and (und("jd_slope_mmd_aer") or und("jd_rmin_mmd_aer")):
+                fail(23132, "-AER.MMD.JD.slope and -AER.MMD.JD.rmin must be defined")
+            if not one_wl:
+                if und("rn_waref") or und("in_waref"):
+                    fail(2314, "-AER.MMD.MRwaref and -AER.MMD.MIwaref must be defined when -SOS_Main.Wa differs from -AER.Waref")
+            else:
+                p["rn_waref"], p["in_waref"] = p["rn_wa"], p["in_wa"]
+        if imod == 1:
+            if und("imodele_wmo"):
+                fail(2315, "-AER.WMO.Model must be defined")
+            if not 1 <= int(p["imodele_wmo"]) <= 4:
+                fail(2316, "-AER.WMO.Model must be in 1..4")
+            if int(p["imodele_wmo"]) == 4 and any(und(k) for k in ("c_wmo_dl", "c_wmo_ws", "c_wmo_oc", "c_wmo_so")):
+                fail(2317, "-AER.WMO.DL, .WS, .OC and .SO must be defined for the user WMO model")
+        if imod == 2:
+            if und("imodele_sf"):
+                fail(2318, "-AER.SF.Model must be defined")
+            if und("rh"):
+                fail(2319, "-AER.SF.RH must be defined")
+            if not 1 <= int(p["imodele_sf"]) <= 4:
+                fail(2320, "-AER.SF.Model must be in 1..4")
+            if p["rh"] < 0.0 or p["rh"] > 99.0:
+                fail(2321, "-AER.SF.RH must be in [0, 99] %")
+        if imod == 3:
+            if und("mode_param_bilnd"):
+                fail(2322, "-AER.BMD.VCdef must be defined")
+            if int(p["mode_param_bilnd"]) not in (1, 2):
+                fail(2323, "-AER.BMD.VCdef must be 1 or 2")
+            if int(p["mode_param_bilnd"]) == 1:
+                if und("user_cv_coarse"):
+                    fail(2324, "-AER.BMD.CoarseVC must be defined")
+                if und("user_cv_fine"):
+                    fail(2325, "-AER.BMD.FineVC must be defined")
+            if int(p["mode_param_bilnd"]) == 2 and und("rtauct_waref"):
+                fail(2326, "-AER.BMD.RAOT must be defined")
+            if any(und("bmd_cm_" + k) for k in ("mrwa", "miwa", "rmodal", "var")):
+                fail(2327, "the coarse-mode parameters -AER.BMD.CM.{MRwa, MIwa, SDradius, SDvar} must be defined")
+            if any(und("bmd_fm_" + k) for k in ("mrwa", "miwa", "rmodal", "var")):
+                fail(2328, "the fine-mode parameters -AER.BMD.FM.{MRwa, MIwa, SDradius, SDvar} must be defined")
+            if not one_wl:
+                if any(und(k) for k in ("bmd_cm_mrwaref", "bmd_cm_miwaref", "bmd_fm_mrwaref", "bmd_fm_miwaref")):
+                    fail(2329, "-AER.BMD.{CM,FM}.{MRwaref, MIwaref} must be defined when -SOS_Main.Wa differs from -AER.Waref")
+            else:
+                for m in ("cm", "fm"):
+                    p["bmd_%s_mrwaref" % m], p["bmd_%s_miwaref" % m] = p["bmd_%s_mrwa" % m], p["bmd_%s_miwa" % m]
+        if imod == 4:
+            if str(p["ficextdata_aer"]).strip() == "NO_USER_AEROSOLS_PHAZE_FCT":
+                fail(2330, "-AER.ExtData (file of external phase functions) must be defined")
+            if not one_wl:
+                fail(2331, "-AER.Model 4 requires -SOS_Main.Wa equal to -AER.Waref")
+        if imod == 5 and str(p["ficmixture_aer"]).strip() == "NO_USER_AEROSOLS_MIXTURE":
+            fail(2340, "-AER.DefMixture (file of the user mixture) must be defined")
+    if p["aot_ref"] > 0.0 and user_aer:
+        if p["wa_simu"] != p["waref_aot"]:
+            fail(2350, "-AER.UserFile requires -SOS_Main.Wa equal to -AER.Waref")
+        if str(p["ficgranu"]).strip() != SOS_DEFAULT_FICGRANU:
+            fail(2351, "-AER.ResFile must keep its default value when -AER.UserFile is given")
+    if und("rho"):
+        fail(2401, "-SURF.Alb must be defined")
+    if p["rho"] < 0.0:
+        fail(2402, "-SURF.Alb must be positive or null")
+    if und("isurf"):
+        fail(2403, "-SURF.Type must be defined")
+    isurf = int(p["isurf"])
+    if isurf not in range(8):
+        fail(2404, "-SURF.Type must be in 0..7")
+    if und("surf_ind") and isurf in (1, 2, 4, 5, 6, 7):
+        fail(2405, "-SURF.Ind (refractive index of the surface) must be defined for this surface type")
+    if isurf == 1:
+        if und("wind"):
+            fail(2406, "-SURF.Glitter.Wind must be defined")
+        if p["wind"] < 0.0:
+            fail(24061, "-SURF.Glitter.Wind must be positive or null")
+    if isurf >= 3 and any(und(k) for k in ("k0_roujean", "k1_roujean", "k2_roujean")):
+        fail(2407, "-SURF.Roujean.K0, .K1 and .K2 must be defined")
+    if isurf == 7 and und("coef_c_maignan"):
+        fail(2411, "-SURF.Maignan.C must be defined")
+    if not und("tr") and p["tr"] < 0.0:
+        fail(2502, "-AP.MOT must be positive or null")
+    if not und("tr") and p["tr"] > 0.0:                   # (with -AP.MOT left to the Rayleigh formula the reference skips these two)
+        if und("hr"):
+            fail(2503, "-AP.HR (molecular scale height) must be defined")
+        if p["hr"] <= 0.0:
+            fail(2504, "-AP.HR must be strictly positive")
+    if und("iprofil"):
+        fail(2505, "-AP.AerProfile.Type must be defined")
+    if int(p["iprofil"]) not in (1, 2):
+        fail(2506, "-AP.AerProfile.Type must be 1 or 2")
+    if int(p["iprofil"]) == 1:
+        if und("ha") and p["aot_ref"] > 0.0:
+            fail(2507, "-AP.AerHS.HA (aerosol scale height) must be defined")
+        if p["ha"] <= 0.0 and p["aot_ref"] >= 0.0:           # as written there: an undefined HA (-999) fails even without aerosols
+            fail(2508, "-AP.AerHS.HA must be strictly positive")
+    if int(p["iprofil"]) == 2 and (und("zmin") or und("zmax")):
+        fail(2509, "-AP.AerLayer.Zmin and -AP.AerLayer.Zmax must be defined for -AP.AerProfile.Type 2")
+    if und("absprofil"):
+        fail(2510, "-AP.AbsProfile.Type must be defined")
+    absprofil = int(p["absprofil"])
+    if not 0 <= absprofil <= 7:
+        fail(2511, "-AP.AbsProfile.Type must be in 0..7")
+    if absprofil == 0 and str(p["ficabsprofil"]).strip() == "NO_USER_ABS_PROFILE_FILE":
+        fail(2512, "-AP.AbsProfile.UserFile must be defined for -AP.AbsProfile.Type 0")
+    if int(p["iprofil"]) == 2 and absprofil != 7:
+        fail(2513, "-AP.AerProfile.Type 2 requires -AP.AbsProfile.Type 7 (no gas absorption)")
+    if absprofil != 7:
+        if und("nustep"):
+            fail(2514, "-AP.SpectralResol must be defined (1, 5 or 10 cm-1)")
+        if int(p["nustep"]) not in (1, 5, 10):
+            fail(25141, "-AP.SpectralResol must be 1, 5 or 10 cm-1")
+        if und("imode_ckd_calcul"):
+            fail(2515, "-SOS.AbsModeCKD must be defined")
+    if p["igmax"] != _I and int(p["igmax"]) < 1:
+        fail(2604, "-SOS.IGmax must be at least 1")
+    if und("itrphi"):
+        fail(2605, "-SOS.View must be defined")
+    if int(p["itrphi"]) not in (1, 2):
+        fail(2606, "-SOS.View must be 1 or 2")
+    if int(p["itrphi"]) == 1 and und("phios"):
+        fail(2607, "-SOS.View.Phi must be defined for -SOS.View 1")
+    if int(p["itrphi"]) == 2:
+        if und("pas_phi"):
+            fail(2608, "-SOS.View.Dphi must be defined for -SOS.View 2")
+        if int(p["pas_phi"]) <= 0:
+            fail(2609, "-SOS.View.Dphi must be strictly positive")
+    if int(p["ipolar"]) not in (0, 1):
+        fail(2610, "-SOS.Ipolar must be 0 or 1")
+    if (p["zout"] < 0.0 and p["zout"] != -1.0) or p["zout"] > CTE_TOA_ALT:
+        fail(2611, "-SOS.OutputAlt must be -1 (standard levels) or within [0, %g] km" % CTE_TOA_ALT)
+
+
 def sos_proc(aer_phase=None, device=0, **kw):
     """Drop-in for `sos.sos_proc(**kwargs)` (f2py of SOS_PROC, SOS_PROC.F:415) on the MI355X hot path.
     Returns the reference's 23-tuple (names in OUTPUT_NAMES).
@@ -436,6 +613,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
     if missing:
         raise TypeError("sos_proc() missing keyword arguments: %s" % ", ".join(missing))
     p = dict(kw)
+    validate_parameters(p)
     from .solver import SosContext, SosBinError
     from . import surface as _surface
     from . import absorption as _abs

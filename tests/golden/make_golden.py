@@ -265,6 +265,109 @@ def gen_aer_models(only=None):
               "coef_tronca", out[-1], "i_up[0,:3]", out[5][0, :3])
 
 
+# Parameter validation: the error number the reference's SOS_PROC prints for each broken parameter set.
+_VALBASE = {"-SOS_Main.Wa": 0.55, "-ANG.Rad.NbGauss": 8, "-ANG.Thetas": 30.0, "-AP.Psurf": 1013.0, "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0,
+            "-AP.AbsProfile.Type": 7, "-AER.AOTref": 0.0, "-SURF.Type": 0, "-SURF.Alb": 0.1, "-SOS.View": 1, "-SOS.View.Phi": 0.0,
+            "-SOS.IGmax": 3}
+_VAL_LND = {"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 0, "-AER.MMD.SDtype": 1, "-AER.MMD.LNDradius": 0.1,
+            "-AER.MMD.LNDvar": 0.46, "-AER.MMD.MRwa": 1.45, "-AER.MMD.MIwa": -0.001, "-ANG.Aer.NbGauss": 8}
+_VAL_BI = {"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 3, "-AER.BMD.VCdef": 2, "-AER.BMD.RAOT": 0.4, "-ANG.Aer.NbGauss": 8,
+           "-AER.BMD.CM.MRwa": 1.35, "-AER.BMD.CM.MIwa": -0.001, "-AER.BMD.CM.SDradius": 0.8, "-AER.BMD.CM.SDvar": 0.6,
+           "-AER.BMD.FM.MRwa": 1.45, "-AER.BMD.FM.MIwa": -0.003, "-AER.BMD.FM.SDradius": 0.1, "-AER.BMD.FM.SDvar": 0.46}
+
+
+def _without(d, *keys):
+    return {k: v for k, v in d.items() if k not in keys}
+
+
+def _m(*ds):
+    out = {}
+    for d in ds:
+        out.update(d)
+    return out
+
+
+VALIDATION_CASES = [
+    _without(_VALBASE, "-AER.AOTref"), dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Model": 0}), _without(_VALBASE, "-SOS_Main.Wa"),
+    dict(_VALBASE, **{"-SOS_Main.Wa": 0.30}), dict(_VALBASE, **{"-SOS_Main.Wa": 4.5}), _without(_VALBASE, "-ANG.Thetas"),
+    dict(_VALBASE, **{"-ANG.Thetas": 90.0}), dict(_VALBASE, **{"-ANG.Thetas": -1.0}),
+    _m(_VALBASE, _VAL_LND, {"-AER.Model": 6}), _m(_VALBASE, _VAL_LND, {"-AER.Tronca": 2}),
+    dict(_VALBASE, **_without(_VAL_LND, "-AER.MMD.MIwa")), _m(_VALBASE, _VAL_LND, {"-AER.MMD.MIwa": 0.01}),
+    dict(_VALBASE, **_without(_VAL_LND, "-AER.MMD.SDtype")), _m(_VALBASE, _VAL_LND, {"-AER.MMD.SDtype": 3}),
+    dict(_VALBASE, **_without(_VAL_LND, "-AER.MMD.LNDvar")),
+    _m(_VALBASE, _without(_VAL_LND, "-AER.MMD.LNDradius", "-AER.MMD.LNDvar"), {"-AER.MMD.SDtype": 2, "-AER.MMD.JD.slope": 4.0}),
+    _m(_VALBASE, _VAL_LND, {"-SOS_Main.Wa": 0.67}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 1}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 1, "-AER.WMO.Model": 5}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 1, "-AER.WMO.Model": 4, "-AER.WMO.DL": 0.5}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 2, "-AER.SF.RH": 50.0}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 2, "-AER.SF.Model": 1}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 2, "-AER.SF.Model": 5, "-AER.SF.RH": 50.0}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 2, "-AER.SF.Model": 1, "-AER.SF.RH": 99.5}),
+    dict(_VALBASE, **_without(_VAL_BI, "-AER.BMD.VCdef")), _m(_VALBASE, _VAL_BI, {"-AER.BMD.VCdef": 3}),
+    _m(_VALBASE, _VAL_BI, {"-AER.BMD.VCdef": 1, "-AER.BMD.FineVC": 0.5}),
+    _m(_VALBASE, _VAL_BI, {"-AER.BMD.VCdef": 1, "-AER.BMD.CoarseVC": 0.5}),
+    dict(_VALBASE, **_without(_VAL_BI, "-AER.BMD.RAOT")), dict(_VALBASE, **_without(_VAL_BI, "-AER.BMD.CM.SDvar")),
+    dict(_VALBASE, **_without(_VAL_BI, "-AER.BMD.FM.MRwa")), _m(_VALBASE, _VAL_BI, {"-SOS_Main.Wa": 0.67}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 4}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 4, "-AER.ExtData": "@GOLDEN/aer_ext_phase_fct.txt",
+                      "-SOS_Main.Wa": 0.67}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.Model": 5}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.UserFile": "/tmp/Aerosols.txt", "-SOS_Main.Wa": 0.67}),
+    dict(_VALBASE, **{"-AER.AOTref": 0.2, "-AER.Waref": 0.55, "-AER.UserFile": "/tmp/Aerosols.txt", "-AER.ResFile": "Mine.txt"}),
+    _without(_VALBASE, "-SURF.Alb"), dict(_VALBASE, **{"-SURF.Alb": -0.1}), dict(_VALBASE, **{"-SURF.Type": 8}),
+    dict(_VALBASE, **{"-SURF.Type": 2}), dict(_VALBASE, **{"-SURF.Type": 1, "-SURF.Ind": 1.34}),
+    dict(_VALBASE, **{"-SURF.Type": 1, "-SURF.Ind": 1.34, "-SURF.Glitter.Wind": -2.0}),
+    dict(_VALBASE, **{"-SURF.Type": 3, "-SURF.Roujean.K0": 0.2, "-SURF.Roujean.K1": 0.05}),
+    dict(_VALBASE, **{"-SURF.Type": 7, "-SURF.Ind": 1.5, "-SURF.Roujean.K0": 0.2, "-SURF.Roujean.K1": 0.05, "-SURF.Roujean.K2": 0.3}),
+    dict(_VALBASE, **{"-SURF.Type": 6, "-SURF.Ind": 1.5, "-SURF.Roujean.K0": 0.2, "-SURF.Roujean.K1": 0.05, "-SURF.Roujean.K2": 0.3}),
+    dict(_VALBASE, **{"-AP.MOT": -0.1}), _without(_VALBASE, "-AP.HR"), dict(_VALBASE, **{"-AP.HR": 0.0}),
+    dict(_VALBASE, **{"-AP.AerProfile.Type": 3}), _m(_VALBASE, _VAL_LND, {"-AP.AerHS.HA": -999.0}),
+    _without(_VALBASE, "-AP.AerHS.HA"), dict(_VALBASE, **{"-AP.AerHS.HA": 0.0}),
+    dict(_VALBASE, **{"-AP.AerProfile.Type": 2, "-AP.AerLayer.Zmin": 1.0}), _without(_VALBASE, "-AP.AbsProfile.Type"),
+    dict(_VALBASE, **{"-AP.AbsProfile.Type": 8}), dict(_VALBASE, **{"-AP.AbsProfile.Type": 0}),
+    dict(_VALBASE, **{"-AP.AerProfile.Type": 2, "-AP.AerLayer.Zmin": 1.0, "-AP.AerLayer.Zmax": 2.0, "-AP.AbsProfile.Type": 2}),
+    dict(_VALBASE, **{"-AP.AbsProfile.Type": 2}), dict(_VALBASE, **{"-AP.AbsProfile.Type": 2, "-AP.SpectralResol": 2}),
+    dict(_VALBASE, **{"-SOS.IGmax": 0}), dict(_VALBASE, **{"-SOS.View": 3}), _without(_VALBASE, "-SOS.View.Phi"),
+    dict(_without(_VALBASE, "-SOS.View.Phi"), **{"-SOS.View": 2}), dict(_without(_VALBASE, "-SOS.View.Phi"), **{"-SOS.View": 2, "-SOS.View.Dphi": 0}),
+    dict(_VALBASE, **{"-SOS.Ipolar": 2}), dict(_VALBASE, **{"-SOS.OutputAlt": -2.0}), dict(_VALBASE, **{"-SOS.OutputAlt": 130.0}),
+]
+
+
+def gen_validation(index=None):
+    """One reference SOS_PROC call per broken parameter set, each in its own process so that the Fortran runtime's
+    standard output can be read back; the fixture keeps the keyword set and the ERROR number the reference printed."""
+    import importlib
+    import json
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    if index is not None:
+        tmp = tempfile.mkdtemp(prefix="sosval_")
+        try:
+            u = resolve_user(VALIDATION_CASES[int(index)])
+            u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF", "-SOS_Main.Log": "NO_LOG_FILE",
+                      "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE", "-SOS.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+            os.environ["SOS_ABS_ROOT"] = "/root/reference"
+            R.sos_proc(list(rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), u), trace=False).items()))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
+    out = []
+    for i, user in enumerate(VALIDATION_CASES):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "validation", str(i)], capture_output=True, text=True)
+        m = re.search(r"SOS_PROC\s*:\s*ERROR_(\d+)", r.stdout)
+        nadal = "Nadal" in r.stdout
+        code = int(m.group(1)) if m else (-6 if nadal else 0)
+        out.append({"user": user, "code": code})
+        print("validation", i, code, {k: v for k, v in user.items() if _VALBASE.get(k, None) != v} or "(base minus a key)")
+    with open(os.path.join(HERE, "validation.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 _CKDBASE = {"-ANG.Thetas": 35.0, "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0, "-AP.SpectralResol": 10.0, "-AP.Psurf": 1013.0,
             "-AER.Waref": 0.550, "-SOS.IGmax": 100, "-SOS.View": 1, "-SOS.View.Phi": 40.0}
 # Multi-bin CKD bands (VERDICT r01 item 2; SURVEY 8c(v)): the reference's own CKD tables under /root/reference/fic.
@@ -472,6 +575,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "validation":
+        gen_validation(sys.argv[2] if len(sys.argv) > 2 else None)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "profile_layer":
         gen_profile_layer(sys.argv[2] if len(sys.argv) > 2 else None)

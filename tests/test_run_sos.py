@@ -82,3 +82,32 @@ def test_sos_proc_vs_reference(gpu_pkg, name):
     kw = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
     out = rs.sos_proc(**kw)
     cases.compare_proc_outputs(rs, out, g)
+
+
+def test_parameter_validation_matches_the_reference_error_numbers(pkg):
+    """run_sos.validate_parameters raises, for each of the 69 broken keyword sets of tests/golden/validation.json, the error
+    number the compiled reference's SOS_PROC printed for the same set (make_golden.py validation: one reference run per set,
+    `ERROR_<n>` parsed from its standard output).  Code 0 = the reference accepted the set; 4700 = it failed later, inside
+    SOS; -6 = its 'Nadal's BPDF model is not supported' exit: validate_parameters lets those through."""
+    rs = pkg.run_sos
+    cases_ = json.load(open(os.path.join(GOLD, "validation.json")))
+    assert len(cases_) >= 69
+    seen = set()
+    for c in cases_:
+        user = {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v) for k, v in c["user"].items()}
+        user["-SOS_Main.ResRoot"] = "/tmp/unused"
+        p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
+        if c["code"] in (0, 4700, -6):
+            rs.validate_parameters(dict(p))
+            continue
+        with pytest.raises(rs.SosProcError) as e:
+            rs.validate_parameters(dict(p))
+        assert e.value.code == c["code"], (c["code"], e.value.code, c["user"])
+        assert "ERROR_%d" % c["code"] in str(e.value)
+        seen.add(c["code"])
+    assert len(seen) >= 60
+    # single-wavelength side effect (SOS_PROC.F:1704-1707): the reference-wavelength indices default to the simulation ones
+    user = dict(cases_[17]["user"], **{"-SOS_Main.Wa": 0.55})
+    p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
+    rs.validate_parameters(p)
+    assert p["rn_waref"] == p["rn_wa"] == 1.45 and p["in_waref"] == p["in_wa"]
