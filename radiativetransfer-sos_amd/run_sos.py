@@ -547,6 +547,10 @@ def validate_parameters(p):
             fail(24061, "-SURF.Glitter.Wind must be positive or null")
     if isurf >= 3 and any(und(k) for k in ("k0_roujean", "k1_roujean", "k2_roujean")):
         fail(2407, "-SURF.Roujean.K0, .K1 and .K2 must be defined")
+    if isurf == 6:                                        # SOS_PROC.F:2203-2208: the reference leaves here, before the later checks
+        e = SosProcError("The Nadal's BPDF model is not supported ==> Select another surface model")
+        e.code = -6
+        raise e
     if isurf == 7 and und("coef_c_maignan"):
         fail(2411, "-SURF.Maignan.C must be defined")
     if not und("tr") and p["tr"] < 0.0:

@@ -88,7 +88,7 @@ def test_parameter_validation_matches_the_reference_error_numbers(pkg):
     """run_sos.validate_parameters raises, for each of the 69 broken keyword sets of tests/golden/validation.json, the error
     number the compiled reference's SOS_PROC printed for the same set (make_golden.py validation: one reference run per set,
     `ERROR_<n>` parsed from its standard output).  Code 0 = the reference accepted the set; 4700 = it failed later, inside
-    SOS; -6 = its 'Nadal's BPDF model is not supported' exit: validate_parameters lets those through."""
+    SOS: validate_parameters lets those through; -6 = its 'Nadal's BPDF model is not supported' exit, taken at the same place."""
     rs = pkg.run_sos
     cases_ = json.load(open(os.path.join(GOLD, "validation.json")))
     assert len(cases_) >= 69
@@ -97,8 +97,12 @@ def test_parameter_validation_matches_the_reference_error_numbers(pkg):
         user = {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v) for k, v in c["user"].items()}
         user["-SOS_Main.ResRoot"] = "/tmp/unused"
         p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
-        if c["code"] in (0, 4700, -6):
+        if c["code"] in (0, 4700):
             rs.validate_parameters(dict(p))
+            continue
+        if c["code"] == -6:
+            with pytest.raises(rs.SosProcError, match="Nadal"):
+                rs.validate_parameters(dict(p))
             continue
         with pytest.raises(rs.SosProcError) as e:
             rs.validate_parameters(dict(p))
