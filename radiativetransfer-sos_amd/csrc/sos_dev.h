@@ -129,7 +129,11 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
                 for (int rt = 0; rt < NA; rt++) f.a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
             if (RAY >= 0 && !fold) f.v = vp[(size_t)m * 64];
         };
-        auto mma = [&](const AFrag &f, const BRaw &b) {
+        // FIRST: the first k-pair of the contraction starts from a zero accumulator given as the inline constant operand of
+        // the MFMA, so the caller's zero fill of the 2 RTWH CT accumulators (32 vector moves per step) disappears
+        auto mma = [&](const AFrag &f, const BRaw &b, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const v4d zero = {0., 0., 0., 0.};
             v2d ba[CT], bb[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
@@ -137,8 +141,8 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
             for (int rt = 0; rt < NA; rt++)
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
-                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].x, ba[ct].x, acc[0][rt][ct], 0, 0, 0);
-                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].x, bb[ct].x, acc[1][rt][ct], 0, 0, 0);
+                    acc[0][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0][rt].x, ba[ct].x, FIRST ? zero : acc[0][rt][ct], 0, 0, 0);
+                    acc[1][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1][rt].x, bb[ct].x, FIRST ? zero : acc[1][rt][ct], 0, 0, 0);
                 }
 #pragma unroll
             for (int rt = 0; rt < NA; rt++)
@@ -156,33 +160,52 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
                 }
             }
         };
+        const std::true_type first;
+        const std::false_type next;
         AFrag f0, f1;
         BRaw b0, b1;
         load_a(f0, 0);
         int m = 0;
         if (PIPE_B) {
             load_b(b0, 0);
+            if (ks2h >= 2) {                                  // peeled first pair of k-pairs
+                load_a(f1, 1);
+                load_b(b1, 1);
+                mma(f0, b0, first);
+                if (2 < ks2h) { load_a(f0, 2); load_b(b0, 2); }
+                mma(f1, b1, next);
+                m = 2;
 #pragma unroll 1
-            for (; m + 1 < ks2h; m += 2) {
-                load_a(f1, m + 1);
-                load_b(b1, m + 1);
-                mma(f0, b0);
-                if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
-                mma(f1, b1);
-            }
-            if (m < ks2h) mma(f0, b0);
+                for (; m + 1 < ks2h; m += 2) {
+                    load_a(f1, m + 1);
+                    load_b(b1, m + 1);
+                    mma(f0, b0, next);
+                    if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
+                    mma(f1, b1, next);
+                }
+                if (m < ks2h) mma(f0, b0, next);
+            } else mma(f0, b0, first);
         } else {
             // four column tiles: one set of B registers (32 VGPRs) -- the second set costs more in spills than it hides
+            if (ks2h >= 2) {
+                load_a(f1, 1);
+                load_b(b0, 0);
+                mma(f0, b0, first);
+                if (2 < ks2h) load_a(f0, 2);
+                load_b(b0, 1);
+                mma(f1, b0, next);
+                m = 2;
 #pragma unroll 1
-            for (; m + 1 < ks2h; m += 2) {
-                load_a(f1, m + 1);
-                load_b(b0, m);
-                mma(f0, b0);
-                if (m + 2 < ks2h) load_a(f0, m + 2);
-                load_b(b0, m + 1);
-                mma(f1, b0);
-            }
-            if (m < ks2h) { load_b(b0, m); mma(f0, b0); }
+                for (; m + 1 < ks2h; m += 2) {
+                    load_a(f1, m + 1);
+                    load_b(b0, m);
+                    mma(f0, b0, next);
+                    if (m + 2 < ks2h) load_a(f0, m + 2);
+                    load_b(b0, m + 1);
+                    mma(f1, b0, next);
+                }
+                if (m < ks2h) { load_b(b0, m); mma(f0, b0, next); }
+            } else { load_b(b0, 0); mma(f0, b0, first); }
         }
         if (fold) {
             // accumulator register 3 of the tile holding prow is row prow + (lane>>4): the projection, in the B-operand
@@ -320,25 +343,51 @@ __host__ __device__ constexpr int sos_ns(int nw, int rtwh) { return (sos_khm(nw,
 // being written to the field and read back.
 struct Order1 { double sva, svr, sfa, sfr; bool fres; };
 
-template <int DI, int U, int FS, int NS, bool O1>
-__device__ __forceinline__ void scan_block(double *&q, const double *&qa, const double *&qd, double mu, double &z, double &sn,
-                                           const double *&lx, int lstr, const Order1 &o1)
+// LDS pointers of the formal solution.  An explicit address space keeps them 32-bit, and lds_pin hides a freshly computed
+// base from the optimiser: DS instructions take an UNSIGNED 16-bit immediate offset, and for the up-going sweep the compiler
+// otherwise keeps the high end of a block as its induction pointer and pays one vector add per access for the negative offsets.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ void lds_pin(lds_f64 *&p)
 {
+    unsigned a = (unsigned)(unsigned long)p;
+    asm volatile("" : "+v"(a));
+    p = (lds_f64 *)(unsigned long)a;
+}
+__device__ __forceinline__ void lds_pin(const lds_f64 *&p)
+{
+    unsigned a = (unsigned)(unsigned long)p;
+    asm volatile("" : "+v"(a));
+    p = (const lds_f64 *)(unsigned long)a;
+}
+
+template <int DI, int U, int FS, int NS, bool O1>
+__device__ __forceinline__ void scan_block(lds_f64 *&q, const lds_f64 *&qa, const lds_f64 *&qd, double mu, double &z, double &sn,
+                                           const lds_f64 *&lx, int lstr, const Order1 &o1)
+{
+    // The up-going sweep (DI < 0) first moves its base pointers to the low end of the block and indexes upwards from there.
+    // LV(u): offset, in levels, of the level reached after u + 1 steps; LA(u): of the layer crossed by step u + 1.
+    if (DI < 0) {
+        q -= U * FS; qa -= (U - 1) * NS; qd -= (U - 1);
+        if (O1) lx -= U;
+        lds_pin(q); lds_pin(qa);
+    }
+#define LV(u) (DI < 0 ? (U - 1 - (u)) : ((u) + 1))
+#define LA(u) (DI < 0 ? (U - 1 - (u)) : (u))
     double av[U], sv[U], cv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = qa[DI * u * NS]; cv[u] = qd[DI * u]; }
+    for (int u = 0; u < U; ++u) { av[u] = qa[LA(u) * NS]; cv[u] = qd[LA(u)]; }
     if (O1) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) sv[u] = o1.sva * lx[DI * (u + 1)] + o1.svr * lx[lstr + DI * (u + 1)];
+        for (int u = 0; u < U; ++u) sv[u] = o1.sva * lx[LV(u)] + o1.svr * lx[lstr + LV(u)];
         if (o1.fres) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                sv[u] = sv[u] + (o1.sfa * lx[2 * lstr + DI * (u + 1)] + o1.sfr * lx[3 * lstr + DI * (u + 1)]);
+                sv[u] = sv[u] + (o1.sfa * lx[2 * lstr + LV(u)] + o1.sfr * lx[3 * lstr + LV(u)]);
         }
-        lx += DI * U;
+        if (DI > 0) lx += U;
     } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) sv[u] = q[DI * (u + 1) * FS];
+        for (int u = 0; u < U; ++u) sv[u] = q[LV(u) * FS];
     }
     double dv[U];
 #pragma unroll
@@ -349,9 +398,12 @@ __device__ __forceinline__ void scan_block(double *&q, const double *&qa, const 
 #pragma unroll
     for (int u = 0; u < U; ++u) { z = cv[u] * dv[u] + (z + av[u] * (sv[u] - z)); cv[u] = z; }
 #pragma unroll
-    for (int u = 0; u < U; ++u) q[DI * (u + 1) * FS] = cv[u];
+    for (int u = 0; u < U; ++u) q[LV(u) * FS] = cv[u];
     sn = sv[U - 1];
-    q += DI * U * FS; qa += DI * U * NS; qd += DI * U;
+    if (DI > 0) { q += U * FS; qa += U * NS; qd += U; }
+    else { qa -= NS; qd -= 1; }
+#undef LV
+#undef LA
 }
 
 // Down-going block of the field-in-HBM variant: the source of U consecutive levels is read from the LDS chunk the

@@ -159,10 +159,10 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
             constexpr bool O1 = decltype(o1_tag)::value;
             // q  -> field at the level the ray has reached, qa -> attenuation of the next layer, qd -> its 1/dtau
             const int i0 = DI < 0 ? nt : 0;
-            double *q = fld + (size_t)i0 * FS + rl;
-            const double *qa = att + (size_t)(DI < 0 ? nt - 1 : 0) * NS + jj;
-            const double *qd = idtau + (DI < 0 ? nt - 1 : 0);
-            const double *lx = cxd + i0;
+            lds_f64 *q = (lds_f64 *)(fld + (size_t)i0 * FS + rl);
+            const lds_f64 *qa = (const lds_f64 *)(att + (size_t)(DI < 0 ? nt - 1 : 0) * NS + jj);
+            const lds_f64 *qd = (const lds_f64 *)(idtau + (DI < 0 ? nt - 1 : 0));
+            const lds_f64 *lx = (const lds_f64 *)(cxd + i0);
             double z = bcv;
             // source at the level the ray comes from (no reflected-beam term there: SOS_OS.F:3280 excludes it)
             double sn = O1 ? o1.sva * lx[0] + o1.svr * lx[LPB] : *q;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                 iglast = ig;
                 // source function of order ig: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
                 {
-                    v4d acc[2][RTWH][CT];
+                    v4d acc[2][RTWH][CT];       // (zero for a bin without aerosol operator; the dense pass starts from the MFMA zero operand)
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++)
 #pragma unroll

@@ -44,17 +44,20 @@ __host__ __device__ inline size_t stream_scratch_doubles(int nw, int rtw, int lp
 }
 
 // Homogeneous part of the up-going field of U levels: P <- P (1 - a), X = Q + P xin (see the header); q, qa move upwards.
+// (bases moved to the low end of the block and pinned: non-negative immediate offsets, see scan_block)
 template <int U, int FS, int NS>
-__device__ __forceinline__ void fix_block(double *&q, const double *&qa, double &P, double xi)
+__device__ __forceinline__ void fix_block(lds_f64 *&q, const lds_f64 *&qa, double &P, double xi)
 {
+    q -= U * FS; qa -= (U - 1) * NS;
+    lds_pin(q); lds_pin(qa);
     double av[U], qv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = qa[-u * NS]; qv[u] = q[-(u + 1) * FS]; }
+    for (int u = 0; u < U; ++u) { av[u] = qa[(U - 1 - u) * NS]; qv[u] = q[(U - 1 - u) * FS]; }
 #pragma unroll
     for (int u = 0; u < U; ++u) { P = P - P * av[u]; qv[u] = qv[u] + P * xi; }
 #pragma unroll
-    for (int u = 0; u < U; ++u) q[-(u + 1) * FS] = qv[u];
-    q -= U * FS; qa -= U * NS;
+    for (int u = 0; u < U; ++u) q[(U - 1 - u) * FS] = qv[u];
+    qa -= NS;
 }
 
 // linear LDS-DMA copy of `units` 16-byte units global -> LDS (wave-uniform LDS base + lane * 16, exec-masked tail)
@@ -314,8 +317,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                     if (active) {
                         const int mid = l0 + (L - l0) / 2;
                         const int lev = up ? L : mid + 1;              // level this thread starts from (already final there)
-                        double *q = cbuf + (size_t)(lev - l0) * FS + kk;          // row kk of the up-going half
-                        const double *qa = catt + (size_t)(lev - l0) * NS + jj;   // layer lev-1
+                        lds_f64 *q = (lds_f64 *)(cbuf + (size_t)(lev - l0) * FS + kk);          // row kk of the up-going half
+                        const lds_f64 *qa = (const lds_f64 *)(catt + (size_t)(lev - l0) * NS + jj);   // layer lev-1
                         double P = up ? 1.0 : pm;                       // attenuation from L up to `lev`
                         int cnt = up ? L - mid - 1 : (L > l0 ? mid - l0 + 1 : 0);
                         if (cnt < 0) cnt = 0;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                     __syncthreads();
                     PH(1);
                     // source function of order ig for the levels of the chunk (SOS_FSOURCE_ORDREIG)
-                    v4d acc[2][RTWH][CT];
+                    v4d acc[2][RTWH][CT];       // (zero for a bin without aerosol operator; the dense pass starts from the MFMA zero operand)
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++)
 #pragma unroll
@@ -373,17 +376,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                 }
                 // formal solution of the chunk, in place (SOS_INTEGR_EPOPT)
                 if (active && !up) {
-                    double *q;
-                    const double *qa, *qd, *lx;
+                    lds_f64 *q;
+                    const lds_f64 *qa, *qd, *lx;
                     int cnt;
+                    lds_f64 *const cb3 = (lds_f64 *)cbuf;
+                    const lds_f64 *const ca3 = (const lds_f64 *)catt, *const ci3 = (const lds_f64 *)cidt, *const cx3 = (const lds_f64 *)ccxd;
                     if (chk == 0) {               // the ray enters at the top: X-(0) = 0, S-(0) is the first "previous" source
-                        q = cbuf + rl; qa = catt + NS + jj; qd = cidt + 1; lx = ccxd + 1;
+                        q = cb3 + rl; qa = ca3 + NS + jj; qd = ci3 + 1; lx = cx3 + 1;
                         dn_z = 0.;
                         dn_s = O1 ? o1.sva * lx[0] + o1.svr * lx[VL] : *q;       // no reflected-beam term at level 0 (SOS_OS.F:3280)
                         *q = 0.;
                         cnt = nlev - 1;
                     } else {
-                        q = cbuf - FS + rl; qa = catt + jj; qd = cidt; lx = ccxd; cnt = nlev;
+                        q = cb3 - FS + rl; qa = ca3 + jj; qd = ci3; lx = cx3; cnt = nlev;
                     }
 #pragma unroll 1
                     for (; cnt >= 8; cnt -= 8) scan_block<1, 8, FS, NS, O1>(q, qa, qd, mu, dn_z, dn_s, lx, VL, o1);
@@ -397,10 +402,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const
                     }
                 } else if (active) {
                     // up-going rows: the chunk with zero inflow at its bottom level L (Q_L = 0), then the link to level l0-1
-                    double *q = cbuf + (size_t)(L - l0) * FS + rl;
-                    const double *qa = catt + (size_t)(L - l0) * NS + jj;          // layer L-1
-                    const double *qd = cidt + (L - l0);
-                    const double *lx = ccxd + (L - l0 + 1);                        // level L
+                    lds_f64 *q = (lds_f64 *)(cbuf + (size_t)(L - l0) * FS + rl);
+                    const lds_f64 *qa = (const lds_f64 *)(catt + (size_t)(L - l0) * NS + jj);          // layer L-1
+                    const lds_f64 *qd = (const lds_f64 *)(cidt + (L - l0));
+                    const lds_f64 *lx = (const lds_f64 *)(ccxd + (L - l0 + 1));                        // level L
                     double sn;
                     if (O1) {
                         sn = o1.sva * lx[0] + o1.svr * lx[VL];

@@ -1,0 +1,81 @@
+"""Worker of tests/test_dist_gpu.py: one rank of a sharded band solve on a real GPU (launched by torch.distributed.run).
+
+Every rank builds the same seeded bin list, solves ITS contiguous slice with SosContext.solve_band (fused solve, AIK-weighted
+aggregate incl. the TDIFMUG tail, ONE all-reduce) and rank 0 compares the band with the unsharded solve of all bins.
+--backend nccl: one GPU per rank (RCCL); --backend gloo: every rank on cuda:0 (the 1-GPU test box), tensors reduced by gloo."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--bins", type=int, default=7)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    dev = local if a.backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+    pkg = importlib.import_module("radiativetransfer-sos_amd")
+    S, D = pkg.synth, pkg.dist
+    import cases
+    c = cases.make_case("aer_n41")
+    rng = np.random.default_rng(7)
+    nb = a.bins
+    # bins: seeded gas absorption on the case's 30-layer grid (S.profile), same rescale as the fixed cases
+    prof = []
+    for kabs in rng.uniform(0.0, 4.0, nb):
+        h_, x_, y_, _ = S.profile(30, k_abs=float(kabs))
+        prof.append(S.rescale_profile(h_, x_, y_, 0.0, 0.95, 0.95, c["os_nb"])[:3])
+    h, xdel, ydel = (np.stack([p[i] for p in prof]) for i in range(3))
+    aik = rng.uniform(0.1, 1.0, nb); aik /= aik.sum()
+    tdif = rng.uniform(0.0, 1.0, (nb, len(c["rmu"])))
+    cx = pkg.SosContext(c["rmu"], c["ga"], c["n0"], *c["coefs"], iborm_max=c["iborm"], ro=0.1, device=dev)
+    lo, hi = D.shard_range(nb, rank, world)
+    sl = slice(lo, hi)
+    bins = cx.upload_bins(h[sl], xdel[sl], ydel[sl])
+    rec, fin = cx.solve_band(bins, torch.as_tensor(aik[sl], device=cx.device),
+                             tdifmug=torch.as_tensor(tdif[sl], device=cx.device))
+    torch.cuda.synchronize()
+    res = {"rank": rank, "world": world, "shard": [lo, hi]}
+    if rank == 0:
+        # the same band without sharding (no process group involved: group of one rank)
+        solo = dist.new_group([0]) if world > 1 else None
+    else:
+        solo = None
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        allb = cx.upload_bins(h, xdel, ydel)
+        out = cx.solve(allb)
+        rec1, scal1 = cx.aggregate(out, torch.as_tensor(aik, device=cx.device), tdifmug=torch.as_tensor(tdif, device=cx.device))
+        fin1 = D.finish_scalars(scal1)
+        r, r1 = rec.cpu().numpy(), rec1.cpu().numpy()
+        scale = np.abs(r1).max()
+        res.update(rec_err=float(np.abs(r - r1).max() / scale), n_orders=[int(fin["n_orders"][0]), int(fin1["n_orders"][0])],
+                   tdifmug_err=float(np.abs(fin["tdifmug"] - fin1["tdifmug"]).max()),
+                   flux_err=float(max(abs(fin["emoins"][0] - fin1["emoins"][0]), abs(fin["eplus"][0] - fin1["eplus"][0]))),
+                   sum_aik=float(fin["sum_aik"][0]), min_orders=int(fin["min_orders"][0]))
+        with open(a.out, "w") as f:
+            json.dump(res, f)
+    cx.close()
+    if world > 1:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
