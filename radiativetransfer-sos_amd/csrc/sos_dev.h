@@ -136,7 +136,11 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
             const v4d zero = {0., 0., 0., 0.};
             v2d ba[CT], bb[CT];
 #pragma unroll
+#ifdef SOS_EXP_NOADD                                       // timing experiment only (wrong physics): upper bound of a pre-combined field
+            for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct]; bb[ct] = b.xm[ct]; }
+#else
             for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
+#endif
 #pragma unroll
             for (int rt = 0; rt < NA; rt++)
 #pragma unroll

@@ -30,7 +30,10 @@
 #define SOS_STREAM_NT 2
 #endif
 namespace {
-constexpr int COLS = 32;      // levels per chunk (two 16-column MFMA tiles)
+#ifndef SOS_STREAM_COLS
+#define SOS_STREAM_COLS 32
+#endif
+constexpr int COLS = SOS_STREAM_COLS;      // levels per chunk (two 16-column MFMA tiles; 16 = experiment: three workgroups per CU)
 constexpr int VPAD = 8;       // level vectors are stored with a +1 offset (entry e = level e-1) and a few spare entries
 }
 
@@ -74,10 +77,10 @@ __device__ __forceinline__ void glds_copy(const double *g, double *l, int units,
 // NW, RTWH, ZO, SURF: as k_sos_os (sos_os.hip).  Two workgroups per CU for NW = 4: while one waits for its chunk the other
 // contracts.
 template <int NW, int RTWH, bool ZO, bool SURF>
-__global__ __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1) void k_sos_stream(const SosDev cx, const SosBins bn)
+__global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void k_sos_stream(const SosDev cx, const SosBins bn)
 {
     extern __shared__ double smem[];
-    constexpr int CT = 2, NTH = 64 * NW, HW = NW / 2;
+    constexpr int CT = COLS / 16, NTH = 64 * NW, HW = NW / 2;
     constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
     constexpr int VL = COLS + VPAD;        // chunk copy of a level vector: entry e = level (layer) l0 - 1 + e
     const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
