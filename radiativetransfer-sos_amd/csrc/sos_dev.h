@@ -295,7 +295,10 @@ __device__ __forceinline__ void ground_mfma(const double *__restrict__ gp, int k
     const size_t rts = (size_t)ks2h * 64;
     const v2d *ap = reinterpret_cast<const v2d *>(gp) + (size_t)tile0 * rts + lane;
     const double *bp = gndk + (lane >> 4);
-    constexpr int MB = 5;                     // k-pairs requested together
+#ifndef SOS_GROUND_MB
+#define SOS_GROUND_MB 5
+#endif
+    constexpr int MB = SOS_GROUND_MB;         // k-pairs requested together
 #pragma unroll 1
     for (int m = 0; m < ks2h; m += MB) {
         v2d a[MB][NA];
