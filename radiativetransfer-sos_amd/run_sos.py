@@ -12,7 +12,8 @@ Scope.  Supported: gas absorption by the CKD method (`-AP.
 `-SOS.AbsModeCKD` modes, all bins of a band solved in one batch) or none (7); aerosols given by the reference's own
 `-AER.UserFile` (an Aerosols.txt) or by the extension keyword `aer_phase`, or none; exponential profiles
 (`-AP.AerProfile.Type 1`); surfaces `-SURF.Type` 0 (Lambert), 1 (+ Cox-Munk glitter), 2 (+ flat sea), 3 (Roujean),
-4 / 5 / 7 (Roujean + Rondeaux-Herman / Breon / Maignan); `-SOS.Trans`, `-SOS.Flux`, `SOS_Result.bin` files.
+4 / 5 / 7 (Roujean + Rondeaux-Herman / Breon / Maignan), or reflection matrices from a user file (`-SURF.File`, the format
+SOS_SURFACE writes); `-SOS.Trans`, `-SOS.Flux`, `SOS_Result.bin` files.
 Every aerosol model of `-AER.Model`: 0 (mono-modal log-normal / Junge), 1 (WMO), 2 (Shettle & Fenn), 3 (bimodal
 log-normal), 4 (external phase functions), 5 (user mixture) -- Mie theory on the GPU (aerosols.py, csrc/mie.hip).
 Both aerosol profiles: exponential (`-AP.AerProfile.Type 1`) and a layer between two altitudes (2; the reference reads an
@@ -425,6 +426,36 @@ def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, 
     return phi_fin, theta_fin, tabs, tabs_dn
 
 
+def read_surface_file(path, n, os_nb):
+    """A surface reflection-matrix file in the reference's format (what SOS_SURFACE writes and SOS_OS reads, SOS_OS.F:916-925):
+    one sequential unformatted record per Fourier order IS = 0..OS_NB holding the nine REAL*4 matrices P11 P12 P13 P21 ...
+    P33, each ((R(I,J), I=1,N), J=1,N).  Returns float32 [os_nb+1][9][N][N] (the layout of SosContext(rsurf=...))."""
+    want = 9 * n * n * 4
+    out = np.zeros((os_nb + 1, 9, n, n), dtype=np.float32)
+    with open(path, "rb") as f:
+        for s in range(os_nb + 1):
+            head = f.read(4)
+            if len(head) < 4:
+                raise SosProcError("surface file %s: %d records, %d expected (OS_NB + 1)" % (path, s, os_nb + 1))
+            nbytes = int(np.frombuffer(head, "<i4")[0])
+            if nbytes != want:
+                raise SosProcError("surface file %s: record of %d bytes, 9 x %d x %d REAL*4 expected -- made for another "
+                                   "angle set?" % (path, nbytes, n, n))
+            out[s] = np.frombuffer(f.read(nbytes), "<f4").reshape(9, n, n)
+            f.read(4)
+    return out
+
+
+def write_surface_file(path, rsurf):
+    """Inverse of read_surface_file (rsurf: float32 [F][9][N][N], e.g. surface.glitter_matrices(...)["rsurf"].cpu())."""
+    rsurf = np.ascontiguousarray(rsurf, dtype="<f4")
+    with open(path, "wb") as f:
+        for s in range(rsurf.shape[0]):
+            payload = rsurf[s].tobytes()
+            m = np.array([len(payload)], "<i4").tobytes()
+            f.write(m + payload + m)
+
+
 def validate_parameters(p):
     """The user-parameter checks of SOS_PROC in the reference's order (SOS_PROC.F:1310-1335, 1540-2475): the first violated
     rule raises SosProcError carrying the reference's error number (`.code`, the label of its message block at
@@ -752,11 +783,18 @@ def sos_proc(aer_phase=None, device=0, **kw):
                                    p["coef_c_maignan"])
     lta = ta == 0.0 or piztr == 0.0                                                  # SOS.F:541-550: IBORM = 2 without aerosols
     iborm = min(2, os_nb) if lta else os_nb
-    if isurf == 1:
+    user_surf = str(p["ficsurf"]).strip()
+    if imat and user_surf != "DEFAULT":
+        # -SURF.File: the user's reflection matrices replace the surface computation (SOS_PROC.F:3186-3189,
+        # SOS_PREPA_OS.F:605-658); the direct-beam terms of SOS_TRPHI still follow -SURF.Type
+        if not os.path.exists(user_surf):
+            raise SosProcError("-SURF.File %s does not exist (SOS_PREPA_OS ERROR_1020)" % user_surf, ier=-1)
+        rsurf = torch.as_tensor(read_surface_file(user_surf, n, os_nb), device=torch.device("cuda", device))
+    elif isurf == 1:
         if p["wind"] == _D:
             raise SosProcError("-SURF.Glitter.Wind must be defined")
         rsurf = _surface.glitter_matrices(mu, ga, p["wind"], p["surf_ind"], os_nb, os_ns, os_nm, device=device)["rsurf"]
-    if land is not None:
+    elif land is not None:
         try:
             rsurf = _surface.land_matrices(land, mu, ga, p["surf_ind"] if isurf >= 4 else 1.0, os_nb, os_ns, os_nm, device=device)
         except ValueError as e:

@@ -67,3 +67,42 @@ def test_sos_proc_land_vs_reference(gpu_pkg, name, tmp_path):
     out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
     # REAL*4 surface matrices with rare last-bit differences enter linearly: 1e-7 relative on the reflected part
     cases.compare_proc_outputs(rs, out, g, coef_tronca=coef, rtol=2e-7)
+
+
+def test_surface_file_round_trip(pkg, tmp_path):
+    rs = pkg.run_sos
+    g = np.load(os.path.join(GOLD, "sos_proc_land_rondeaux.npz"))
+    f = str(tmp_path / "SURF_USER")
+    rs.write_surface_file(f, g["rsurf"])
+    n = g["rsurf"].shape[-1]
+    back = rs.read_surface_file(f, n, g["rsurf"].shape[0] - 1)
+    assert back.dtype == np.float32 and np.array_equal(back, g["rsurf"])
+    assert os.path.getsize(f) == g["rsurf"].shape[0] * (9 * n * n * 4 + 8)          # one unformatted record per Fourier order
+    with pytest.raises(rs.SosProcError):
+        rs.read_surface_file(f, n + 1, 3)                                            # made for another angle set
+    with pytest.raises(rs.SosProcError):
+        rs.read_surface_file(f, n, g["rsurf"].shape[0])                              # one order short
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LAND_CASES)
+def test_sos_proc_with_the_references_surface_file(gpu_pkg, name, tmp_path):
+    """-SURF.File: the reflection matrices come from a user file (here the very file the reference wrote for the case), the
+    surface computation is skipped (SOS_PROC.F:3186-3189).  With bit-identical matrices the radiances match at 1e-9."""
+    rs = gpu_pkg.run_sos
+    g = np.load(os.path.join(GOLD, "sos_proc_%s.npz" % name))
+    user = json.loads(str(g["user_json"]))
+    f = str(tmp_path / "SURF_USER")
+    rs.write_surface_file(f, g["rsurf"])
+    user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT", "-SURF.File": f})
+    coef = None
+    if user["-AER.AOTref"] != 0.0:
+        fa = str(tmp_path / "Aerosols_user.txt")
+        rs.write_aerosols_file(fa, {k: g["aer_" + k] for k in ("alpha", "beta", "gamma", "zeta", "a_tronc", "piztr", "piz")}, *g["kmat"])
+        user["-AER.UserFile"] = fa
+        coef = 0.0
+    out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
+    cases.compare_proc_outputs(rs, out, g, coef_tronca=coef)
+    user["-SURF.File"] = str(tmp_path / "missing")
+    with pytest.raises(rs.SosProcError):
+        rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
