@@ -30,6 +30,11 @@
 #define SOS_STREAM_NT 2
 #endif
 namespace {
+#ifndef SOS_STREAM_PREFETCH
+#define SOS_STREAM_PREFETCH 0      // 1: request chunk c+1 from inside the store pass of chunk c.  Measured 3.4 % SLOWER (21.4 k vs
+                                   // 22.1 k bins/s, profiles/r02_stream_experiments.txt): the per-unit address arithmetic of the
+                                   // requests costs more vector issue than the hidden latency returns.  Kept as an experiment switch.
+#endif
 #ifndef SOS_STREAM_COLS
 #define SOS_STREAM_COLS 32
 #endif
@@ -302,12 +307,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
 #pragma unroll 1
             for (int chk = 0; chk < nchunk; chk++) {
                 const int l0 = chk * COLS, L = min(l0 + COLS - 1, nt), nlev = L - l0 + 1;
-                __syncthreads();                  // the previous chunk has left LDS
                 // stage the chunk: field of order ig-1 (32 levels; the scratch is zero beyond nt), attenuations of layers
-                // l0-1 .. l0+30, level vectors of levels l0-1 .. l0+38
-                if (!O1) glds_copy<NTH, SOS_STREAM_NT>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
-                glds_copy<NTH, 0>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
-                for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + l0 + e % VL];
+                // l0-1 .. l0+30, level vectors of levels l0-1 .. l0+38.  In the passes of order >= 2 every chunk but the first
+                // was already requested by the store pass of the chunk before it (below).
+                if (O1 || !SOS_STREAM_PREFETCH || chk == 0) {
+                    __syncthreads();              // the previous chunk has left LDS
+                    if (!O1) glds_copy<NTH, SOS_STREAM_NT>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
+                    glds_copy<NTH, 0>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
+                    for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + l0 + e % VL];
+                }
                 double xi = 0., pm = 1.;
                 if (!O1 && active) { xi = xin[chk * KHM + kk]; if (!up) pm = pmid[chk * NS + jj]; }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -438,11 +446,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                 }
                 __syncthreads();
                 if (!O1) PH(4);
-                // the chunk [Q+ | X-] of this order goes back to the scratch (levels l0..L only)
+                // the chunk [Q+ | X-] of this order goes back to the scratch (levels l0..L only).  After the barrier above nobody
+                // reads the attenuation / level-vector copies any more, and each 16-byte unit of the chunk is read here by ONE
+                // thread -- the same one the LDS-DMA mapping gives it to: so the next chunk is requested unit by unit as soon as
+                // this thread has sent the old content on its way, with no barrier in between, and its latency runs behind the
+                // store pass instead of in front of the next contraction.
                 {
+                    const bool pre = SOS_STREAM_PREFETCH && !O1 && chk + 1 < nchunk;
                     const int units = nlev * FS / 2;
                     const v2d *src = reinterpret_cast<const v2d *>(cbuf);
                     v2d *dst = reinterpret_cast<v2d *>(fld + (size_t)l0 * FS);
+                    const double *gnx = fld + (size_t)(l0 + COLS) * FS;
+                    auto fetch = [&](int u) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gnx + 2 * (size_t)u),
+                                                         (__attribute__((address_space(3))) void *)(cbuf + 2 * (size_t)(u - (t & 63))), 16, 0,
+                                                         SOS_STREAM_NT);
+                    };
+                    if (pre) {
+                        const int ln = l0 + COLS;
+                        glds_copy<NTH, 0>(att + (size_t)ln * NS, catt, COLS * NS / 2, t);
+                        for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + ln + e % VL];
+                    }
                     int u = t;
 #pragma unroll 1
                     for (; u + 3 * NTH < units; u += 4 * NTH) {
@@ -453,9 +477,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
 #else
                         dst[u] = a0; dst[u + NTH] = a1; dst[u + 2 * NTH] = a2; dst[u + 3 * NTH] = a3;
 #endif
+                        if (pre) { fetch(u); fetch(u + NTH); fetch(u + 2 * NTH); fetch(u + 3 * NTH); }
                     }
 #pragma unroll 1
-                    for (; u < units; u += NTH) dst[u] = src[u];
+                    for (; u < units; u += NTH) {
+                        const v2d a0 = src[u];
+                        dst[u] = a0;
+                        if (pre) fetch(u);
+                    }
                 }
                 if (O1) PH(7); else PH(5);
             }
