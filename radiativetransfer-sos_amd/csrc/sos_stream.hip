@@ -74,13 +74,26 @@ __device__ __forceinline__ void fix_block(lds_f64 *&q, const lds_f64 *&qa, doubl
 template <int NTH, int AUX>
 __device__ __forceinline__ void glds_copy(const double *g, double *l, int units, int t)
 {
-    for (int u = t; u < units; u += NTH)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 2 * (size_t)u),
-                                         (__attribute__((address_space(3))) void *)(l + 2 * (size_t)(u - (t & 63))), 16, 0, AUX);
+    // Wave-uniform trip count and a wave-uniform running base on both sides: the global address is (scalar base + 16 t) and the
+    // LDS base (M0) advances by a constant, so a unit costs scalar instructions only -- no per-lane address arithmetic, no
+    // per-lane loop predicate (vector issue is the scarce resource of this kernel, see sos_dev.h).
+    const char *gb = reinterpret_cast<const char *>(g);
+    // LDS base of this wave as a scalar (M0 is written from it, advanced by scalar adds)
+    const unsigned lb = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(l) + (size_t)(t & ~63) * 16));
+    unsigned toff = (unsigned)t * 16u;
+    const int full = units / NTH, rem = units - full * NTH;
+#pragma unroll 1
+    for (int i = 0; i < full; i++) {
+        asm volatile("" : "+v"(toff));      // keep (scalar base + 32-bit lane offset) apart: the scalar-base addressing form
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + (size_t)i * (NTH * 16) + toff),
+                                         (__attribute__((address_space(3))) void *)(unsigned long)(lb + (unsigned)i * (NTH * 16)), 16, 0, AUX);
+    }
+    if (t < rem)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + (size_t)full * (NTH * 16) + toff),
+                                         (__attribute__((address_space(3))) void *)(unsigned long)(lb + (unsigned)full * (NTH * 16)), 16, 0, AUX);
 }
 
-// NW, RTWH, ZO, SURF: as k_sos_os (sos_os.hip).  Two workgroups per CU for NW = 4: while one waits for its chunk the other
-// contracts.
 template <int NW, int RTWH, bool ZO, bool SURF>
 __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void k_sos_stream(const SosDev cx, const SosBins bn)
 {
