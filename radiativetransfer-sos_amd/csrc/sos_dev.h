@@ -120,14 +120,25 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
     if (do_aer) {
         const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
         const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
-        const v2d *ap = reinterpret_cast<const v2d *>(mp) + (size_t)tile0 * rts + lane;
+        // Operand addresses = wave-uniform byte base (scalar registers, advanced by scalar adds) + the lane's 32-bit offset:
+        // the scalar-base form of global_load needs no vector address arithmetic at all (it was 12 of the 28 non-MFMA vector
+        // instructions per pair of k-pairs).  `loff` is re-hidden from the optimiser at every use so that it is not folded
+        // into a per-lane 64-bit pointer again.
+        const char *ab = reinterpret_cast<const char *>(mp) + (size_t)tile0 * rts * 16;
+        const char *vb = reinterpret_cast<const char *>(vt);
+        unsigned loff = (unsigned)lane * 16u;
         struct AFrag { v2d a[2][NA]; v2d v; };
         auto load_a = [&](AFrag &f, int m) {
+            // (the k-pair offset is hidden as well: derived from the previous call's bases it would need an immediate of
+            // 4096, one more than the instruction can hold, and fall back to vector arithmetic)
+            size_t mb = (size_t)m * 1024;
+            asm volatile("" : "+v"(loff), "+s"(mb));
 #pragma unroll
             for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                for (int rt = 0; rt < NA; rt++) f.a[sy][rt] = ap[sy * sys_stride + (size_t)rt * NW * rts + (size_t)m * 64];
-            if (RAY >= 0 && !fold) f.v = vp[(size_t)m * 64];
+                for (int rt = 0; rt < NA; rt++)
+                    f.a[sy][rt] = *reinterpret_cast<const v2d *>(ab + (sy * sys_stride + (size_t)rt * NW * rts) * 16 + mb + loff);
+            if (RAY >= 0 && !fold) f.v = *reinterpret_cast<const v2d *>(vb + mb + loff);
         };
         // FIRST: the first k-pair of the contraction starts from a zero accumulator given as the inline constant operand of
         // the MFMA, so the caller's zero fill of the 2 RTWH CT accumulators (32 vector moves per step) disappears
@@ -293,7 +304,9 @@ __device__ __forceinline__ void ground_mfma(const double *__restrict__ gp, int k
 #pragma unroll
     for (int rt = 0; rt < NA; rt++) acc[rt] = 0.;
     const size_t rts = (size_t)ks2h * 64;
-    const v2d *ap = reinterpret_cast<const v2d *>(gp) + (size_t)tile0 * rts + lane;
+    // scalar byte base + 32-bit lane offset, as in gemm_source: scalar-base loads, no vector address arithmetic
+    const char *ab = reinterpret_cast<const char *>(gp) + (size_t)tile0 * rts * 16;
+    unsigned loff = (unsigned)lane * 16u;
     const double *bp = gndk + (lane >> 4);
 #ifndef SOS_GROUND_MB
 #define SOS_GROUND_MB 5
@@ -306,8 +319,10 @@ __device__ __forceinline__ void ground_mfma(const double *__restrict__ gp, int k
 #pragma unroll
         for (int u = 0; u < MB; u++) {
             const int mm = min(m + u, ks2h - 1);
+            size_t mb = (size_t)mm * 1024;
+            asm volatile("" : "+v"(loff), "+s"(mb));
 #pragma unroll
-            for (int rt = 0; rt < NA; rt++) a[u][rt] = ap[(size_t)rt * NW * rts + (size_t)mm * 64];
+            for (int rt = 0; rt < NA; rt++) a[u][rt] = *reinterpret_cast<const v2d *>(ab + (size_t)rt * NW * rts * 16 + mb + loff);
             b0[u] = bp[8 * mm]; b1[u] = bp[8 * mm + 4];
         }
 #pragma unroll
