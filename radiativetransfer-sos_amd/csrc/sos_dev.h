@@ -285,6 +285,46 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
     }
 }
 
+
+// Write-back of the source function: S+ = E^A + E^B, stored S- = E^A - E^B (see the storage convention above), one 16 x 16
+// accumulator tile per (row tile, column tile): lane (column lane&15, row quad lane>>4) stores rows 4e + (lane>>4) of its tile.
+// No lane predicates: pad rows (< KH) and pad columns of the accumulators are exact zeros (zero operator rows, zero field
+// columns) and are stored as such.  Row tiles beyond KH are skipped by WAVE-UNIFORM tests; a wave whose tiles all lie inside
+// the half system (every wave at N = 41) takes the straight-line form -- the per-store tests of the general form cost two
+// vector instructions and a branch each.
+template <int RTWH, int CT, int NW, int FS, int KHM>
+__device__ __forceinline__ void write_back_source(const v4d (&acc)[2][RTWH][CT], double *cbuf, int lane, int wv, int kh)
+{
+    double *wb = cbuf + (lane & 15) * FS + (lane >> 4) + wv * 16;
+    if ((wv + (RTWH - 1) * NW) * 16 + 16 <= kh) {
+#pragma unroll
+        for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                    wb[ct * 16 * FS + rt * NW * 16 + 4 * e] = ea + eb;
+                    wb[ct * 16 * FS + KHM + rt * NW * 16 + 4 * e] = ea - eb;
+                }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < RTWH; rt++) {
+            // rows of this tile inside the half system (kh is a multiple of 8, register e holds rows 4e..4e+3 of the tile)
+            const int ne = (kh - (wv + rt * NW) * 16) >> 2;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (e < ne) {
+                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                        wb[ct * 16 * FS + rt * NW * 16 + 4 * e] = ea + eb;
+                        wb[ct * 16 * FS + KHM + rt * NW * 16 + 4 * e] = ea - eb;
+                    }
+        }
+    }
+}
+
 // Ground reflection of the down-going field of the previous scattering order by a BRDF/BPDF surface (SOS_OS.F:1194-1220):
 //   X_a(NT, k) = (2/mu_k) sum_j w_j sum_b X_b(NT, -j) R_ab(j, k)            (+ the Lambertian term on I for s = 0)
 // a 3N x 3N matrix-vector product per scattering order.  As per-thread dot products over REAL*4 matrices in L2 it cost as much

@@ -324,27 +324,7 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                     else if (fold) __syncthreads();                            // the barrier of the folded projection
                     __syncthreads();             // every wave has read the field
                     PH(2);
-                    // S+ = E^A + E^B, stored S- = E^A - E^B.  No lane predicates: pad rows (< KH) and pad columns of the
-                    // accumulators are exact zeros (zero operator rows, zero field columns) and are stored as such.
-                    {
-                        double *wb = cbuf + (lane & 15) * FS + (lane >> 4);
-#pragma unroll
-                        for (int rt = 0; rt < RTWH; rt++) {
-                            const int tile = wv + rt * NW;
-                            // rows of this tile inside the half system (KH is a multiple of 8, register e holds
-                            // rows 4e..4e+3 of the tile): a wave-uniform count, no lane predicate
-                            const int ne = (KH - tile * 16) >> 2;
-#pragma unroll
-                            for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                                for (int e = 0; e < 4; e++)
-                                    if (e < ne) {
-                                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
-                                        wb[ct * 16 * FS + tile * 16 + 4 * e] = ea + eb;
-                                        wb[ct * 16 * FS + KHM + tile * 16 + 4 * e] = ea - eb;
-                                    }
-                        }
-                    }
+                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH);
                     __syncthreads();
                 }
                 PH(3);

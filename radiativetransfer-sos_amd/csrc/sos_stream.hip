@@ -378,23 +378,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                     else if (fold) __syncthreads();
                     __syncthreads();             // every wave has read the chunk
                     PH(2);
-                    {
-                        double *wb = cbuf + (lane & 15) * FS + (lane >> 4);
-#pragma unroll
-                        for (int rt = 0; rt < RTWH; rt++) {
-                            const int tile = wv + rt * NW;
-                            const int ne = (KH - tile * 16) >> 2;
-#pragma unroll
-                            for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                                for (int e = 0; e < 4; e++)
-                                    if (e < ne) {
-                                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
-                                        wb[ct * 16 * FS + tile * 16 + 4 * e] = ea + eb;
-                                        wb[ct * 16 * FS + KHM + tile * 16 + 4 * e] = ea - eb;
-                                    }
-                        }
-                    }
+                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH);
                     __syncthreads();
                     PH(3);
                 }
