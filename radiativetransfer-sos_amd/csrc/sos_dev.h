@@ -17,6 +17,17 @@
 #define PH(k) do {} while (0)
 #endif
 
+// Global address = wave-uniform base (scalar registers) + a 32-bit per-lane byte offset.  The offset is re-hidden from the
+// optimiser at every use: folded into a per-lane 64-bit pointer it would cost two or three vector instructions per access,
+// kept apart the access uses the scalar-base addressing form and costs none (vector issue is the scarce resource here).
+template <typename T>
+__device__ __forceinline__ T *lane_ptr(T *ubase, unsigned &voff)
+{
+    asm volatile("" : "+v"(voff));
+    // (pointer arithmetic, not integer: the address space of ubase must stay visible or a flat access is generated)
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(ubase)) + voff);
+}
+
 // Force a value the whole wave agrees on into scalar registers, so that the loop exits it decides are
 // uniform branches (keeps s / ig / operator pointers in SGPRs instead of per-lane VGPRs).
 __device__ __forceinline__ double uniform_f64(double v)

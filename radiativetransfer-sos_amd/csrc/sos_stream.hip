@@ -313,6 +313,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         const double *ufp = cx.mp_uf + (size_t)(s <= 2 ? s : 0) * cx.rtph * 64;
         const bool fold = s <= 2 && has_aer && cx.prow >= 0;
 
+        // per-lane byte offsets of the scalar-base accesses (lane_ptr); level-vector staging: entry e of the 7 x VL chunk copy
+        // comes from vector e / VL at level l0 - 1 + e % VL -- the split is per-thread constant, only l0 moves
+        unsigned kk8 = (unsigned)kk * 8u, jj8 = (unsigned)jj * 8u;
+        unsigned vso0 = (unsigned)(((t / VL) * VS + t % VL) * 8), vso1 = (unsigned)((((t + NTH) / VL) * VS + (t + NTH) % VL) * 8);
+        auto stage_vec = [&](int lv) {
+            static_assert(7 * VL <= 2 * NTH, "two entries per thread at most");
+            if (t < 7 * VL) cvec[t] = *lane_ptr(vec + lv, vso0);
+            if (t + NTH < 7 * VL) cvec[t + NTH] = *lane_ptr(vec + lv, vso1);
+        };
+
         // ---- one pass over the chunks = one scattering order (O1: the single-scattering source, formed on the fly) ----
         auto pass = [&](auto o1_tag, double bcv) {
             constexpr bool O1 = decltype(o1_tag)::value;
@@ -327,10 +337,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                     __syncthreads();              // the previous chunk has left LDS
                     if (!O1) glds_copy<NTH, SOS_STREAM_NT>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
                     glds_copy<NTH, 0>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
-                    for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + l0 + e % VL];
+                    stage_vec(l0);
                 }
                 double xi = 0., pm = 1.;
-                if (!O1 && active) { xi = xin[chk * KHM + kk]; if (!up) pm = pmid[chk * NS + jj]; }
+                if (!O1 && active) { xi = *lane_ptr(xin + chk * KHM, kk8); if (!up) pm = *lane_ptr(pmid + chk * NS, jj8); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (!O1) PH(0);
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                         // A(c): one more layer step (layer l0-1, source of level l0-1 kept from the previous chunk) on Q_l0
                         const double a = catt[jj];
                         const double w = a * (mu * cidt[0] + 1.0) - 1.0;
-                        acf[chk * KHM + kk] = w * (sn - up_sprev) + (z + a * (up_sprev - z));
+                        *lane_ptr(acf + chk * KHM, kk8) = w * (sn - up_sprev) + (z + a * (up_sprev - z));
                     }
                     up_sprev = sbot;
                     if (ZO && jout) {
@@ -462,25 +472,42 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                     if (pre) {
                         const int ln = l0 + COLS;
                         glds_copy<NTH, 0>(att + (size_t)ln * NS, catt, COLS * NS / 2, t);
-                        for (int e = t; e < 7 * VL; e += NTH) cvec[e] = vec[(size_t)(e / VL) * VS + ln + e % VL];
+                        stage_vec(ln);
                     }
-                    int u = t;
-#pragma unroll 1
-                    for (; u + 3 * NTH < units; u += 4 * NTH) {
-                        const v2d a0 = src[u], a1 = src[u + NTH], a2 = src[u + 2 * NTH], a3 = src[u + 3 * NTH];
+                    // wave-uniform trip count; global address = scalar base + one of two per-lane 32-bit offsets (the 4 KiB
+                    // step between consecutive units of a thread exceeds the immediate range, so odd units use v1 = v0 + 16 NTH
+                    // and every second pair a second scalar base): no vector address arithmetic (lane_ptr, sos_dev.h)
+                    const int full = units / NTH, rem = units - full * NTH;
+                    char *db = reinterpret_cast<char *>(dst);
+                    unsigned v0 = (unsigned)t * 16u, v1 = (unsigned)t * 16u + (unsigned)(NTH * 16);
+                    const v2d *sp = src + t;
+                    auto put = [&](const v2d &a, char *base, unsigned &vo) {
+                        v2d *d = reinterpret_cast<v2d *>(lane_ptr(base, vo));
 #if SOS_STREAM_NT
-                        __builtin_nontemporal_store(a0, &dst[u]); __builtin_nontemporal_store(a1, &dst[u + NTH]);
-                        __builtin_nontemporal_store(a2, &dst[u + 2 * NTH]); __builtin_nontemporal_store(a3, &dst[u + 3 * NTH]);
+                        __builtin_nontemporal_store(a, d);
 #else
-                        dst[u] = a0; dst[u + NTH] = a1; dst[u + 2 * NTH] = a2; dst[u + 3 * NTH] = a3;
+                        *d = a;
 #endif
-                        if (pre) { fetch(u); fetch(u + NTH); fetch(u + 2 * NTH); fetch(u + 3 * NTH); }
+                    };
+                    int i = 0;
+#pragma unroll 1
+                    for (; i + 4 <= full; i += 4) {
+                        const v2d a0 = sp[(i + 0) * NTH], a1 = sp[(i + 1) * NTH], a2 = sp[(i + 2) * NTH], a3 = sp[(i + 3) * NTH];
+                        size_t o0 = (size_t)i * (NTH * 16), o1 = o0 + 2 * (NTH * 16);
+                        asm volatile("" : "+s"(o1));
+                        put(a0, db + o0, v0); put(a1, db + o0, v1); put(a2, db + o1, v0); put(a3, db + o1, v1);
+                        if (pre) { fetch(t + i * NTH); fetch(t + (i + 1) * NTH); fetch(t + (i + 2) * NTH); fetch(t + (i + 3) * NTH); }
                     }
 #pragma unroll 1
-                    for (; u < units; u += NTH) {
-                        const v2d a0 = src[u];
-                        dst[u] = a0;
-                        if (pre) fetch(u);
+                    for (; i < full; i++) {
+                        const v2d a0 = sp[i * NTH];
+                        put(a0, db + (size_t)i * (NTH * 16), v0);
+                        if (pre) fetch(t + i * NTH);
+                    }
+                    if (t < rem) {
+                        const v2d a0 = sp[full * NTH];
+                        put(a0, db + (size_t)full * (NTH * 16), v0);
+                        if (pre) fetch(t + full * NTH);
                     }
                 }
                 if (O1) PH(7); else PH(5);
