@@ -247,7 +247,10 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
                     }
                 }
         }
-        // XDEL of the output level: every accumulator register of a lane belongs to one column
+        // XDEL of the output level: every accumulator register of a lane belongs to one column.  Without a molecular term
+        // (RAY < 0: Fourier orders > 2) the factor is applied by the write-back instead, fused into its sums
+        // (write_back_source: 3 instead of 4 vector instructions per accumulator pair).
+        if (RAY >= 0)
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             const double sc = xdel[ct * 16 + (lane & 15)];
@@ -303,11 +306,30 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 // columns) and are stored as such.  Row tiles beyond KH are skipped by WAVE-UNIFORM tests; a wave whose tiles all lie inside
 // the half system (every wave at N = 41) takes the straight-line form -- the per-store tests of the general form cost two
 // vector instructions and a branch each.
+// xdel != nullptr (wave-uniform): the accumulators are still unscaled (gemm_source with RAY < 0 and an aerosol operator);
+// S+ = x ea + x eb, S- = x ea - x eb as one product and two fused multiply-adds.
 template <int RTWH, int CT, int NW, int FS, int KHM>
-__device__ __forceinline__ void write_back_source(const v4d (&acc)[2][RTWH][CT], double *cbuf, int lane, int wv, int kh)
+__device__ __forceinline__ void write_back_source(const v4d (&acc)[2][RTWH][CT], double *cbuf, int lane, int wv, int kh,
+                                                  const double *xdel)
 {
     double *wb = cbuf + (lane & 15) * FS + (lane >> 4) + wv * 16;
     if ((wv + (RTWH - 1) * NW) * 16 + 16 <= kh) {
+        if (xdel) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const double sc = xdel[ct * 16 + (lane & 15)];
+#pragma unroll
+                for (int rt = 0; rt < RTWH; rt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                        const double p = sc * ea;
+                        wb[ct * 16 * FS + rt * NW * 16 + 4 * e] = __builtin_fma(sc, eb, p);
+                        wb[ct * 16 * FS + KHM + rt * NW * 16 + 4 * e] = __builtin_fma(-sc, eb, p);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int rt = 0; rt < RTWH; rt++)
 #pragma unroll
@@ -319,6 +341,9 @@ __device__ __forceinline__ void write_back_source(const v4d (&acc)[2][RTWH][CT],
                     wb[ct * 16 * FS + KHM + rt * NW * 16 + 4 * e] = ea - eb;
                 }
     } else {
+        double sc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) sc[ct] = xdel ? xdel[ct * 16 + (lane & 15)] : 1.0;
 #pragma unroll
         for (int rt = 0; rt < RTWH; rt++) {
             // rows of this tile inside the half system (kh is a multiple of 8, register e holds rows 4e..4e+3 of the tile)
@@ -328,7 +353,7 @@ __device__ __forceinline__ void write_back_source(const v4d (&acc)[2][RTWH][CT],
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     if (e < ne) {
-                        const double ea = acc[0][rt][ct][e], eb = acc[1][rt][ct][e];
+                        const double ea = sc[ct] * acc[0][rt][ct][e], eb = sc[ct] * acc[1][rt][ct][e];
                         wb[ct * 16 * FS + rt * NW * 16 + 4 * e] = ea + eb;
                         wb[ct * 16 * FS + KHM + rt * NW * 16 + 4 * e] = ea - eb;
                     }

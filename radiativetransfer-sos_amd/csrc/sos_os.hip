@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                     }
                 }
                 if (cx.ifresnel == 1) {
-                    const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
+                    unsigned jj8 = (unsigned)jj * 8u;                 // scalar base + lane offset: no vector address arithmetic
+                    const double f11 = *lane_ptr(cx.fres, jj8), f12 = *lane_ptr(cx.fres + N, jj8), f33 = *lane_ptr(cx.fres + 2 * N, jj8);
                     const double *g0 = SURF ? gnd + kk - c * gstep : gnd + jj;      // (I, jj); Q and U follow at gs, 2 gs
                     const int gs = SURF ? gstep : NS;
                     if (c == 0) v = v + f11 * g0[0] + f12 * g0[gs];
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                     else if (fold) __syncthreads();                            // the barrier of the folded projection
                     __syncthreads();             // every wave has read the field
                     PH(2);
-                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH);
+                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH, (s > 2 && has_aer) ? xdel : nullptr);
                     __syncthreads();
                 }
                 PH(3);

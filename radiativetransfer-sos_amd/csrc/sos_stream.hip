@@ -283,7 +283,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                 }
             }
             if (cx.ifresnel == 1) {
-                const double f11 = cx.fres[jj], f12 = cx.fres[N + jj], f33 = cx.fres[2 * N + jj];
+                unsigned jf8 = (unsigned)jj * 8u;
+                const double f11 = *lane_ptr(cx.fres, jf8), f12 = *lane_ptr(cx.fres + N, jf8), f33 = *lane_ptr(cx.fres + 2 * N, jf8);
                 const double *g0 = SURF ? gnd + kk - c * gstep : gnd + jj;
                 const int gs = SURF ? gstep : NS;
                 if (c == 0) v = v + f11 * g0[0] + f12 * g0[gs];
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                     else if (fold) __syncthreads();
                     __syncthreads();             // every wave has read the chunk
                     PH(2);
-                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH);
+                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH, (s > 2 && has_aer) ? cxdel + 1 : nullptr);
                     __syncthreads();
                     PH(3);
                 }
@@ -522,20 +523,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int cc = max(cq - u, 1);
-                        av[u] = acf[cc * KHM + kk]; bv[u] = bcf[cc * NS + jj];
+                        av[u] = *lane_ptr(acf + cc * KHM, kk8); bv[u] = *lane_ptr(bcf + cc * NS, jj8);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         if (cq - u >= 1) {
-                            xin[(cq - u) * KHM + kk] = x;
+                            *lane_ptr(xin + (cq - u) * KHM, kk8) = x;
                             if (ZO && jout) { if (cq - u == jlo / COLS) xlo = qlo + plo * x; if (cq - u == jhi / COLS) xhi = qhi + phi * x; }
                             x = av[u] + bv[u] * x;
                         }
                     cq -= 8;
                 }
-                xin[kk] = x;
+                *lane_ptr(xin, kk8) = x;
                 if (ZO && jout) { if (jlo / COLS == 0) xlo = qlo + plo * x; if (jhi / COLS == 0) xhi = qhi + phi * x; }
-                xb = q_top + bcf[jj] * x;
+                xb = q_top + *lane_ptr(bcf, jj8) * x;
             }
         };
 
