@@ -53,6 +53,13 @@ def lib():
             raise RuntimeError(
                 "libsosgpu.so not found at %s: the HIP extension is required (no CPU fallback). "
                 "Run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950)." % SO_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 and this library links against the system's.  Loaded
+        # first, the system runtime would be initialised here and torch's copy afterwards -- two runtimes, and the later one
+        # sees no device.  Importing torch first makes both resolve to the runtime torch loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
         L.sosgpu_strerror.restype = C.c_char_p
