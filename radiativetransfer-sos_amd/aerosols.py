@@ -46,8 +46,9 @@ def _round_sig(x, sig):
 def mie_angles(nb_gauss):
     """Mie angle set without user angles: positive Gauss nodes of the 2 nb_gauss-point rule, ascending, as re-read from
     Aer_UsedAngles.txt (D21.14).  Returns xmu[-N:N], xhr[-N:N] as arrays of 2N+1 (index j + N; entry N unused = 0)."""
-    x, w = np.polynomial.legendre.leggauss(2 * nb_gauss)
-    mu, wt = _round_sig(x[nb_gauss:], 14), _round_sig(w[nb_gauss:], 14)
+    from .run_sos import sos_gauss
+    x, w = sos_gauss(nb_gauss)                             # the reference's own Gauss-Legendre routine (SOS_ANGLES.F:1022)
+    mu, wt = _round_sig(x, 14), _round_sig(w, 14)
     n = nb_gauss
     xmu, xhr = np.zeros(2 * n + 1), np.zeros(2 * n + 1)
     xmu[n + 1:], xhr[n + 1:] = mu, wt

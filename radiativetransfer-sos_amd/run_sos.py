@@ -211,6 +211,68 @@ def write_used_angles(path, mu, ga, n0, ind_ang, nb_gauss, tetas, os_nb, os_ns, 
             f.write("%4d " % (j + 1) + fortran_d(mu[j], 21, 14) + fortran_d(ga[j], 21, 14) + " %4d\n" % ind_ang[j])
 
 
+def sos_gauss(nb_gauss):
+    """SOS_GAUSS (SOS_ANGLES.F:1022-1103) for MM = nb_gauss + 1: the positive nodes and weights of the 2 nb_gauss-point
+    Gauss-Legendre rule, ascending in the cosine -- the reference's own Newton iteration (asymptotic start, three-term
+    recurrence, stop at |dx| <= 1e-15), statement for statement, so that the D21.14 digits of the angle files agree in
+    their last place too (numpy's leggauss differs from it by an ulp here and there)."""
+    n = 2 * nb_gauss
+    pi = math.pi
+    aa = 2.0 / pi ** 2
+    ab = -62.0 / (3.0 * pi ** 4)
+    ac = 15116.0 / (15.0 * pi ** 6)
+    ad = -12554474.0 / (105.0 * pi ** 8)
+    en = float(n)
+    u = 1.0 - (2.0 / pi) ** 2
+    d = 1.0 / math.sqrt((en + 0.5) ** 2 + u / 4.0)
+    r, w = [], []
+    for k in range(1, n + 1):
+        az = 4.0 * k - 1.0
+        z = 0.25 * pi * (az + aa / az + ab / az ** 3 + ac / az ** 5 + ad / az ** 7)
+        x = math.cos(z * d)
+        while True:
+            pm2, pm1 = 1.0, x                              # PA(1), PA(2)
+            for nn in range(3, n + 2):
+                enn = nn - 1.0
+                pm2, pm1 = pm1, ((2.0 * enn - 1.0) * x * pm1 - (enn - 1.0) * pm2) / enn
+            pnp = en * (pm2 - x * pm1) / (1.0 - x * x)     # PA(N), PA(NP1)
+            xi = x - pm1 / pnp
+            if abs(xi - x) - 1.0e-15 <= 0.0:
+                r.append(x)
+                w.append(2.0 * (1.0 - x * x) / (en * pm2) ** 2)
+                break
+            x = xi
+    # R(I), I = 1..MM-1, descend from the largest node: AMU(K = MM - I) -> ascending cosines for K = 1..nb_gauss
+    mu = np.array([r[i] for i in range(nb_gauss)][::-1])
+    wt = np.array([w[i] for i in range(nb_gauss)][::-1])
+    return mu, wt
+
+
+def write_mie_angles(path, nb_gauss, os_nb, user_file="NO_USER_ANGLES"):
+    """`Aer_UsedAngles.txt` (SOS_ANGLES.F:367-376, rows `I4,1X,2D21.14`): the Gauss nodes of the phase-function angle set plus
+    the user's angles (weight 0), cosines ascending."""
+    x, w = sos_gauss(nb_gauss)
+    mu, wt = list(x), list(w)
+    if user_file != "NO_USER_ANGLES":
+        with open(user_file) as f:
+            for line in f:
+                if line.strip():
+                    val = float(line.split()[0])
+                    if val < 0. or val > 90.:
+                        raise SosProcError("user angle out of [0,90] in %s" % user_file)
+                    mu.append(math.cos(val * math.pi / 180.))
+                    wt.append(0.0)
+    order = np.argsort(np.asarray(mu), kind="stable")
+    with open(path, "w") as f:
+        f.write("NB_TOTAL_ANGLES :%4d\n" % len(mu))
+        f.write("NB_GAUSS_ANGLES :%4d\n" % nb_gauss)
+        f.write("ANGLES_USERFILE :" + user_file.ljust(CTE_LENFIC2) + "\n")
+        f.write("INTERNAL_OS_NB :%4d\n" % os_nb)
+        f.write("INDEX   COS_ANGLE            WEIGHT\n")
+        for i, j in enumerate(order):
+            f.write("%4d " % (i + 1) + fortran_d(mu[j], 21, 14) + fortran_d(wt[j], 21, 14) + "\n")
+
+
 # ---------------------------------------------------------------------------------------------------------
 # host-side restatements of the steps before the hot path (inputs of SOS_OS)
 # ---------------------------------------------------------------------------------------------------------
@@ -219,9 +281,9 @@ def angles(nbmu_gauss, tetas, user_file="NO_USER_ANGLES"):
     2*NbGauss-point rule on [-1,1] (positive half), optional user angles (weight 0), solar angle inserted
     with weight 0 unless it coincides with a node, mu descending; values as re-read from SOS_UsedAngles.txt
     (D21.14).  Returns mu[N], ga[N], n0 (1-based), ind_angout[N] (1 = user angle)."""
-    x, w = np.polynomial.legendre.leggauss(2 * nbmu_gauss)
-    mu = list(x[nbmu_gauss:])
-    wt = list(w[nbmu_gauss:])
+    x, w = sos_gauss(nbmu_gauss)
+    mu = list(x)
+    wt = list(w)
     if user_file != "NO_USER_ANGLES":
         with open(user_file) as f:
             for line in f:
@@ -863,9 +925,18 @@ def sos_proc(aer_phase=None, device=0, **kw):
         resroot = str(p["resroot"]).strip()
         if resroot:                                   # SOS_PROC.F:1342-1500: results under RESROOT/SOS
             os.makedirs(os.path.join(resroot, "SOS"), exist_ok=True)
+            # the two angle files SOS_ANGLES always writes (SOS_ANGLES.F:367-376, 494-506)
+            write_mie_angles(os.path.join(resroot, "SOS", str(p["ficangles_res_mie"]).strip()), nb_mie, os_nb,
+                             str(p["ficangles_user_mie"]).strip())
+            write_used_angles(os.path.join(resroot, "SOS", str(p["ficangles_res_lum"]).strip()), mu, ga, n0, ind_ang, nb_lum,
+                              p["tetas"], os_nb, os_ns, os_nm, str(p["ficangles_user_lum"]).strip())
             if use_model:
                 write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()), aer_phase, aer_phase["kmat1"],
                                     aer_phase["kmat2"])
+            elif p["aot_ref"] == 0.0:                 # SOS_AEROSOLS writes an all-zero file for an aerosol-free run
+                z = np.zeros(os_nb + 1)
+                write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()),
+                                    dict(alpha=z, beta=z, gamma=z, zeta=z, a_tronc=0.0, piztr=0.0, piz=0.0))
             write_result_bin(os.path.join(resroot, "SOS", resbin), rec[0, :nf].cpu().numpy())
     finally:
         ctx.close()

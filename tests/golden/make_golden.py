@@ -335,6 +335,33 @@ VALIDATION_CASES = [
 ]
 
 
+def gen_angle_files():
+    """The text files SOS_ANGLES / SOS_AEROSOLS write for a tiny case with user angles in both angle sets
+    (SOS_UsedAngles.txt, Aer_UsedAngles.txt, and the Aerosols.txt of an aerosol-free run)."""
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    tmp = tempfile.mkdtemp(prefix="sosang_")
+    try:
+        uf = os.path.join(tmp, "user_ang.txt")
+        open(uf, "w").write("10.0\n47.5\n")
+        user = dict(_VALBASE, **{"-ANG.Rad.NbGauss": 4, "-ANG.Aer.NbGauss": 5, "-ANG.Rad.UserAngFile": "@USERANG", "-ANG.Aer.UserAngFile": "@USERANG"})
+        u = {k: (uf if v == "@USERANG" else v) for k, v in user.items()}
+        u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF", "-SOS_Main.Log": "NO_LOG_FILE",
+                  "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE", "-SOS.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+        R.sos_proc(list(rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), u), trace=False).items()))
+        files = {}
+        for nm in ("Aer_UsedAngles.txt", "SOS_UsedAngles.txt", "Aerosols.txt"):
+            files[nm] = open(os.path.join(tmp, "SOS", nm)).read().replace(uf, "@USERANG")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(HERE, "angle_files.json"), "w") as f:
+        json.dump({"user": user, "user_angles_deg": [10.0, 47.5], "files": files}, f, indent=0)
+    print("angle_files", {k: len(v) for k, v in files.items()})
+
+
 def gen_validation(index=None):
     """One reference SOS_PROC call per broken parameter set, each in its own process so that the Fortran runtime's
     standard output can be read back; the fixture keeps the keyword set and the ERROR number the reference printed."""
@@ -575,6 +602,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "angle_files":
+        gen_angle_files()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "validation":
         gen_validation(sys.argv[2] if len(sys.argv) > 2 else None)

@@ -36,7 +36,9 @@ def test_decompo_legendre_recovers_a_known_expansion(pkg):
     P = np.polynomial.legendre.legval(xmu, beta)
     z = np.zeros_like(P)
     d = A.decompo_legendre(0, xmu, xhr, nb, P, z, P.copy(), z)
-    assert np.allclose(d["beta"], beta / beta[0], rtol=0, atol=1e-12) and d["coef_tronca"] == 0.0 and d["itronc"] == 0
+    # (1e-10: the nodes and weights are the reference's own -- SOS_GAUSS stops its Newton iteration at 1e-15 in the node and
+    # its weights carry 1e-14 .. 1e-13 of that; numpy's leggauss would give 1e-12 here)
+    assert np.allclose(d["beta"], beta / beta[0], rtol=0, atol=1e-10) and d["coef_tronca"] == 0.0 and d["itronc"] == 0
 
 
 @pytest.mark.gpu

@@ -115,3 +115,26 @@ def test_parameter_validation_matches_the_reference_error_numbers(pkg):
     p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
     rs.validate_parameters(p)
     assert p["rn_waref"] == p["rn_wa"] == 1.45 and p["in_waref"] == p["in_wa"]
+
+
+def test_angle_and_aerosol_text_files_match_the_reference(pkg, tmp_path):
+    """SOS_UsedAngles.txt, Aer_UsedAngles.txt (user angles in both sets) and the Aerosols.txt of an aerosol-free run, byte for
+    byte as the compiled reference wrote them (tests/golden/angle_files.json, make_golden.py angle_files); only the padded
+    user-file name differs."""
+    rs = pkg.run_sos
+    d = json.load(open(os.path.join(GOLD, "angle_files.json")))
+    uf = str(tmp_path / "user_ang.txt")
+    open(uf, "w").write("".join("%.1f\n" % a for a in d["user_angles_deg"]))
+    nb_lum, nb_mie = d["user"]["-ANG.Rad.NbGauss"], d["user"]["-ANG.Aer.NbGauss"]
+    os_nb, os_ns = 2 * nb_mie, 2 * nb_lum
+    mu, ga, n0, ind = rs.angles(nb_lum, d["user"]["-ANG.Thetas"], uf)
+    rs.write_used_angles(str(tmp_path / "lum.txt"), mu, ga, n0, ind, nb_lum, d["user"]["-ANG.Thetas"], os_nb, os_ns, os_nb + os_ns, uf)
+    rs.write_mie_angles(str(tmp_path / "mie.txt"), nb_mie, os_nb, uf)
+    z = np.zeros(os_nb + 1)
+    rs.write_aerosols_file(str(tmp_path / "aer.txt"), dict(alpha=z, beta=z, gamma=z, zeta=z, a_tronc=0.0, piztr=0.0, piz=0.0))
+
+    def lines(text):
+        return [ln.rstrip() for ln in text.replace(uf, "@USERANG").splitlines()]
+    assert lines(open(tmp_path / "lum.txt").read()) == lines(d["files"]["SOS_UsedAngles.txt"])
+    assert lines(open(tmp_path / "mie.txt").read()) == lines(d["files"]["Aer_UsedAngles.txt"])
+    assert lines(open(tmp_path / "aer.txt").read()) == lines(d["files"]["Aerosols.txt"])
