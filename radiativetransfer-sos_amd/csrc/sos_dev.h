@@ -45,12 +45,8 @@ __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_read
 // call is enough -- the barrier also publishes whatever the caller wrote to LDS/scratch before).  No FP64 work.
 // (__syncthreads_or only returns a logical OR.)
 template <int NW>
-__device__ __forceinline__ int block_or_bits(int bits, int *red, int wv, int lane, int &slot)
+__device__ __forceinline__ int block_or_word(int w, int *red, int wv, int lane, int &slot)
 {
-    int w = 0;
-    if (__ballot(bits & 1)) w |= 1;
-    if (__ballot(bits & 2)) w |= 2;
-    if (__ballot(bits & 4)) w |= 4;
     int *r = red + slot * NW;
     slot ^= 1;
     if (lane == 0) r[wv] = w;
@@ -59,6 +55,22 @@ __device__ __forceinline__ int block_or_bits(int bits, int *red, int wv, int lan
 #pragma unroll
     for (int i = 0; i < NW; i++) o |= r[i];
     return uniform_i32(o);
+}
+// The predicates are passed as such: a comparison leaves its result as a wave mask in scalar registers, and "any lane" of it
+// is a scalar test -- packing them into per-lane bits first and unpacking them for the ballots cost a dozen vector instructions.
+template <int NW>
+__device__ __forceinline__ int block_or_bits(bool b1, bool b2, bool b4, int *red, int wv, int lane, int &slot)
+{
+    int w = 0;
+    if (__ballot(b1)) w |= 1;
+    if (__ballot(b2)) w |= 2;
+    if (__ballot(b4)) w |= 4;
+    return block_or_word<NW>(w, red, wv, lane, slot);
+}
+template <int NW>
+__device__ __forceinline__ int block_or_bits(bool b1, int *red, int wv, int lane, int &slot)
+{
+    return block_or_word<NW>(__ballot(b1) ? 1 : 0, red, wv, lane, slot);
 }
 
 // Instruction budget.  FP64 vector instructions share the FP64 datapath with v_mfma_f64 on gfx950 (equal peak

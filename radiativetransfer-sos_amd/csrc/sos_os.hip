@@ -269,15 +269,12 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                     PH(1);                                   // formal solution without its barrier wait (that goes to 4)
                     g1 = xb;
                     const double i3n = i3 + g1;
-                    int pm = 0;
-                    if (active) {
-                        if (ig != 2 && conv_exceeds(a1, d1, g1, i3, cx.thr_cv)) pm |= 1;     // SOS_PARAM_CONV
-                        const double ag = fabs(g1);
-                        if (ag > cx.thr_val) pm |= 2;                                       // SOS_ARRET_DIFFUS_1
-                        if (i3n != 0.0 && ag > cx.thr_sum * fabs(i3n)) pm |= 4;             // SOS_ARRET_DIFFUS_2
-                    }
+                    const double ag = fabs(g1);
+                    const bool p1 = active && ig != 2 && conv_exceeds(a1, d1, g1, i3, cx.thr_cv);       // SOS_PARAM_CONV
+                    const bool p2 = active && ag > cx.thr_val;                                          // SOS_ARRET_DIFFUS_1
+                    const bool p4 = active && i3n != 0.0 && ag > cx.thr_sum * fabs(i3n);                // SOS_ARRET_DIFFUS_2
                     // the barrier inside also ends the formal solution: field and ground values are complete after it
-                    pm = block_or_bits<NW>(pm, reinterpret_cast<int *>(red), wv, lane, red_slot);
+                    const int pm = block_or_bits<NW>(p1, p2, p4, reinterpret_cast<int *>(red), wv, lane, red_slot);
                     PH(4);
                     bc = ground_bc();
                     PH(5);
@@ -367,12 +364,9 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
             }
             if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
             nord = s + 1;
-            int pf2 = 0;                                                             // SOS_ARRET_FOURIER
-            if (active) {
-                const double a3 = fabs(i3);
-                if ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5))) pf2 = 1;
-            }
-            pf2 = block_or_bits<NW>(pf2, reinterpret_cast<int *>(red), wv, lane, red_slot);
+            const double a3 = fabs(i3);                                                             // SOS_ARRET_FOURIER
+            const bool pf = active && ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5)));
+            const int pf2 = block_or_bits<NW>(pf, reinterpret_cast<int *>(red), wv, lane, red_slot);
             PH(6);
             if (!pf2) break;                                                         // SOS_OS.F:1585
         }
