@@ -7,6 +7,16 @@
 #include "sos_common.h"
 
 #define SOSGPU_E_UNSUPPORTED -3
+// Parity sums X+ +- X- of the B operands: formed by every wave inside the contraction (8 vector sums per k-pair and wave), or
+// once per step / chunk in LDS.  Measured (profiles/r02_flagship_instmix.txt): in the LDS-resident kernel the combine pass needs
+// a workgroup barrier of its own and LOSES 2.1 % (194.1 vs 198.2 k bins/s) -- off; in the streamed kernel it rides in the
+// fix-up pass that closes the up-going rows anyway, no barrier added: +0.5 % -- on.
+#ifndef SOS_PRECOMBINE_LDS
+#define SOS_PRECOMBINE_LDS 0
+#endif
+#ifndef SOS_PRECOMBINE_STREAM
+#define SOS_PRECOMBINE_STREAM 1
+#endif
 #ifdef SOS_PROFILE_PHASES
 // s_memrealtime: constant 100 MHz counter (s_memtime is NOT wall-clock on gfx950 when waves share a SIMD: it advances
 // at 1/k of the shader clock with k MFMA-streaming waves per SIMD -- scripts/ubench_mfma_peak.hip)
@@ -118,7 +128,7 @@ __device__ __forceinline__ double queue_term(double d, double g)
 // L2 nor the LDS round trip sits between two k-pairs.  The rank-4 projection of the molecular operator (RAY = half
 // system it acts on, -1 = none) either comes for free (FOLD: its four rows are packed into padding rows of the dense
 // operator) or rides in the same loop as 2 CT extra MFMAs per k-pair fed by one more prefetched 16-byte fragment.
-template <int NA, int RAY, bool FOLD, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B>
+template <int NA, int RAY, bool FOLD, int RTWH, int CT, int NW, int FS, int KHM, bool PIPE_B, bool PRE = false>
 __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const double *__restrict__ mp, bool do_aer,
                                             const double *__restrict__ vt, const double *__restrict__ uf,
                                             int ks2h, int rtph, const double *bx, const double *xdel,
@@ -170,11 +180,12 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
             const v4d zero = {0., 0., 0., 0.};
             v2d ba[CT], bb[CT];
 #pragma unroll
-#ifdef SOS_EXP_NOADD                                       // timing experiment only (wrong physics): upper bound of a pre-combined field
-            for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct]; bb[ct] = b.xm[ct]; }
-#else
-            for (int ct = 0; ct < CT; ct++) { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
-#endif
+            // PRE: the buffer already holds X^A = X+ + X- where X+ used to be and X^B = X+ - X- where X- used to be (combined
+            // once per step for all four waves instead of by every wave for itself: 8 sums per k-pair and wave less)
+            for (int ct = 0; ct < CT; ct++) {
+                if (PRE) { ba[ct] = b.xp[ct]; bb[ct] = b.xm[ct]; }
+                else { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
+            }
 #pragma unroll
             for (int rt = 0; rt < NA; rt++)
 #pragma unroll
@@ -279,7 +290,7 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
         auto prj = [&](const v2d &v, const BRaw &b) {
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                const v2d bq = RAY ? b.xp[ct] - b.xm[ct] : b.xp[ct] + b.xm[ct];
+                const v2d bq = PRE ? (RAY ? b.xm[ct] : b.xp[ct]) : (RAY ? b.xp[ct] - b.xm[ct] : b.xp[ct] + b.xm[ct]);
                 pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, bq.x, pr[ct], 0, 0, 0);
                 pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, bq.y, pr[ct], 0, 0, 0);
             }
@@ -311,6 +322,27 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
     }
 }
 
+
+
+// Parity combination of the whole field buffer in place, once per step (flagship: between the stop tests and the contraction;
+// one more workgroup barrier after it): wave w takes levels w, w + NW, ..., a lane two adjacent rows of both halves.
+template <int NW, int FS, int KHM, int LEVELS>
+__device__ __forceinline__ void combine_field(double *fld, int lane, int wv)
+{
+    static_assert(KHM == 128 || KHM == 64 || KHM == 256, "rows per half");
+#pragma unroll
+    for (int l = 0; l < LEVELS / NW; l++) {
+        double *row = fld + (size_t)(wv + l * NW) * FS;
+#pragma unroll
+        for (int r = 0; r < KHM; r += 128) {
+            if (KHM >= 128 || lane < KHM / 2) {
+                v2d *pp = reinterpret_cast<v2d *>(row + r + 2 * lane), *pm = reinterpret_cast<v2d *>(row + KHM + r + 2 * lane);
+                const v2d xp = *pp, xm = *pm;
+                *pp = xp + xm; *pm = xp - xm;
+            }
+        }
+    }
+}
 
 // Write-back of the source function: S+ = E^A + E^B, stored S- = E^A - E^B (see the storage convention above), one 16 x 16
 // accumulator tile per (row tile, column tile): lane (column lane&15, row quad lane>>4) stores rows 4e + (lane>>4) of its tile.

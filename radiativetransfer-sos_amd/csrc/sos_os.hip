@@ -294,6 +294,11 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                 if (ig > cx.igmax) break;
                 iglast = ig;
                 // source function of order ig: dense FP64 contraction on the matrix cores (SOS_FSOURCE_ORDREIG)
+                if (SOS_PRECOMBINE_LDS) {
+                    // X^A, X^B formed once for the four waves (sos_dev.h combine_field); the barrier ends the pass
+                    combine_field<NW, FS, KHM, CT * 16>(fld, lane, wv);
+                    __syncthreads();
+                }
                 {
                     v4d acc[2][RTWH][CT];       // (zero for a bin without aerosol operator; the dense pass starts from the MFMA zero operand)
 #pragma unroll
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                     auto contract = [&](auto na_tag) {
                         constexpr int NA = decltype(na_tag)::value;
 #define SOS_GEMM(RAYV, FOLDV)                                                                                          \
-    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, (CT < 4)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,        \
+    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, (CT < 4), (SOS_PRECOMBINE_LDS != 0)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,        \
                                                         xdel, ydel, lane, wv, cx.prow, pcb)
                         if (s > 2) SOS_GEMM(-1, false);
                         else if (s & 1) { if (fold) SOS_GEMM(1, true); else SOS_GEMM(1, false); }

@@ -53,18 +53,28 @@ __host__ __device__ inline size_t stream_scratch_doubles(int nw, int rtw, int lp
 
 // Homogeneous part of the up-going field of U levels: P <- P (1 - a), X = Q + P xin (see the header); q, qa move upwards.
 // (bases moved to the low end of the block and pinned: non-negative immediate offsets, see scan_block)
-template <int U, int FS, int NS>
+// KHM > 0: the closed level is stored in parity form at once, X^A = X+ + X- in its own slot and X^B = X+ - X- in the slot of
+// the down-going row with the same index (KHM doubles further): the contraction that follows reads its B operands without
+// forming the sums (SOS_PRECOMBINE_STREAM), and no extra pass or barrier is needed -- every (row, level) of the chunk is closed here
+// by exactly one thread.
+template <int U, int FS, int NS, int KHM>
 __device__ __forceinline__ void fix_block(lds_f64 *&q, const lds_f64 *&qa, double &P, double xi)
 {
     q -= U * FS; qa -= (U - 1) * NS;
     lds_pin(q); lds_pin(qa);
-    double av[U], qv[U];
+    double av[U], qv[U], xm[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = qa[(U - 1 - u) * NS]; qv[u] = q[(U - 1 - u) * FS]; }
+    for (int u = 0; u < U; ++u) {
+        av[u] = qa[(U - 1 - u) * NS]; qv[u] = q[(U - 1 - u) * FS];
+        if (KHM) xm[u] = q[(U - 1 - u) * FS + KHM];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) { P = P - P * av[u]; qv[u] = qv[u] + P * xi; }
 #pragma unroll
-    for (int u = 0; u < U; ++u) q[(U - 1 - u) * FS] = qv[u];
+    for (int u = 0; u < U; ++u) {
+        if (KHM) { q[(U - 1 - u) * FS] = qv[u] + xm[u]; q[(U - 1 - u) * FS + KHM] = qv[u] - xm[u]; }
+        else q[(U - 1 - u) * FS] = qv[u];
+    }
     qa -= NS;
 }
 
@@ -357,12 +367,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                         double P = up ? 1.0 : pm;                       // attenuation from L up to `lev`
                         int cnt = up ? L - mid - 1 : (L > l0 ? mid - l0 + 1 : 0);
                         if (cnt < 0) cnt = 0;
-                        if (up) *q = xi;                                // level L: Q = 0, X = Xin
+                        if (up) {                                       // level L: Q = 0, X = Xin
+                            if (SOS_PRECOMBINE_STREAM) { const double xm = q[KHM]; q[0] = xi + xm; q[KHM] = xi - xm; }
+                            else *q = xi;
+                        }
 #pragma unroll 1
-                        for (; cnt >= 8; cnt -= 8) fix_block<8, FS, NS>(q, qa, P, xi);
-                        if (cnt & 4) fix_block<4, FS, NS>(q, qa, P, xi);
-                        if (cnt & 2) fix_block<2, FS, NS>(q, qa, P, xi);
-                        if (cnt & 1) fix_block<1, FS, NS>(q, qa, P, xi);
+                        for (; cnt >= 8; cnt -= 8) fix_block<8, FS, NS, SOS_PRECOMBINE_STREAM ? KHM : 0>(q, qa, P, xi);
+                        if (cnt & 4) fix_block<4, FS, NS, SOS_PRECOMBINE_STREAM ? KHM : 0>(q, qa, P, xi);
+                        if (cnt & 2) fix_block<2, FS, NS, SOS_PRECOMBINE_STREAM ? KHM : 0>(q, qa, P, xi);
+                        if (cnt & 1) fix_block<1, FS, NS, SOS_PRECOMBINE_STREAM ? KHM : 0>(q, qa, P, xi);
                     }
                     __syncthreads();
                     PH(1);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                     auto contract = [&](auto na_tag) {
                         constexpr int NA = decltype(na_tag)::value;
 #define SOS_GEMM(RAYV, FOLDV)                                                                                          \
-    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, true>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,            \
+    gemm_source<NA, RAYV, FOLDV, RTWH, CT, NW, FS, KHM, true, (SOS_PRECOMBINE_STREAM != 0)>(acc, mpa, has_aer != 0, vtp, ufp, cx.ks2h, cx.rtph, bx,            \
                                                         cxdel + 1, cydel + 1, lane, wv, cx.prow, pcb)
                         if (s > 2) SOS_GEMM(-1, false);
                         else if (s & 1) { if (fold) SOS_GEMM(1, true); else SOS_GEMM(1, false); }
