@@ -222,6 +222,26 @@ AER_MODEL_CASES = {
     "ext_phase_fct": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-AER.Model": 4, "-AER.ExtData": "@GOLDEN/aer_ext_phase_fct.txt"}),
     # user mixture LND + Junge + LND, 0.865 um
     "mixture_3modes_865": dict(_MODBASE, **{"-SOS_Main.Wa": 0.865, "-AER.Model": 5, "-AER.DefMixture": "@GOLDEN/aer_mixture.txt"}),
+    # ---- parameter combinations not covered elsewhere -------------------------------------------------------------------
+    # mono-modal Junge size distribution, two wavelengths, scalar run (no polarisation), glitter, output at 1.5 km
+    "junge_2wl_nopolar_glitter": dict(_MODBASE, **{"-SOS_Main.Wa": 0.443, "-AER.Model": 0, "-AER.MMD.SDtype": 2, "-AER.MMD.JD.slope": 4.0,
+                                                   "-AER.MMD.JD.rmin": 0.05, "-AER.MMD.JD.rmax": 8.0, "-AER.MMD.MRwa": 1.40,
+                                                   "-AER.MMD.MIwa": -0.002, "-AER.MMD.MRwaref": 1.39, "-AER.MMD.MIwaref": -0.003,
+                                                   "-SOS.Ipolar": 0, "-SURF.Type": 1, "-SURF.Alb": 0.0, "-SURF.Ind": 1.34,
+                                                   "-SURF.Glitter.Wind": 4.0, "-SOS.OutputAlt": 1.5}),
+    # bimodal log-normal with user volume concentrations (VCdef 1), two wavelengths, user viewing angles, polar view
+    "bilnd_vc1_2wl_userangles": dict(_MODBASE, **{"-SOS_Main.Wa": 0.865, "-AER.Model": 3, "-AER.BMD.VCdef": 1, "-AER.BMD.CoarseVC": 0.3,
+                                                  "-AER.BMD.FineVC": 0.7, "-AER.BMD.CM.MRwa": 1.36, "-AER.BMD.CM.MIwa": -0.001,
+                                                  "-AER.BMD.CM.MRwaref": 1.37, "-AER.BMD.CM.MIwaref": -0.001, "-AER.BMD.CM.SDradius": 0.7,
+                                                  "-AER.BMD.CM.SDvar": 0.65, "-AER.BMD.FM.MRwa": 1.44, "-AER.BMD.FM.MIwa": -0.004,
+                                                  "-AER.BMD.FM.MRwaref": 1.45, "-AER.BMD.FM.MIwaref": -0.005, "-AER.BMD.FM.SDradius": 0.09,
+                                                  "-AER.BMD.FM.SDvar": 0.5, "-ANG.Rad.UserAngFile": "@GOLDEN/user_angles.txt",
+                                                  "-SOS.View": 2, "-SOS.View.Dphi": 90}),
+    # few scattering orders allowed (IGMAX reached everywhere), LND, no truncation, Roujean + Breon land surface
+    "lnd_igmax3_breon": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-AER.Model": 0, "-AER.MMD.SDtype": 1, "-AER.MMD.LNDradius": 0.2,
+                                          "-AER.MMD.LNDvar": 0.5, "-AER.MMD.MRwa": 1.5, "-AER.MMD.MIwa": -0.01, "-AER.Tronca": 0,
+                                          "-SOS.IGmax": 3, "-SURF.Type": 5, "-SURF.Alb": 0.0, "-SURF.Ind": 1.5, "-SURF.Roujean.K0": 0.25,
+                                          "-SURF.Roujean.K1": 0.04, "-SURF.Roujean.K2": 0.3}),
 }
 
 

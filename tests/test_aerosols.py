@@ -59,7 +59,8 @@ def test_aerosol_model_vs_reference_aerosols_file(gpu_pkg, name):
         assert abs(got["coef_tronca"] - float(g["coef_tronca"])) <= 2e-6
 
 
-MODEL_CASES = ["wmo_continental", "wmo_user_865", "sf_maritime_rh70", "sf_urban_rh0", "ext_phase_fct", "mixture_3modes_865"]
+MODEL_CASES = ["wmo_continental", "wmo_user_865", "sf_maritime_rh70", "sf_urban_rh0", "ext_phase_fct", "mixture_3modes_865",
+               "junge_2wl_nopolar_glitter", "bilnd_vc1_2wl_userangles", "lnd_igmax3_breon"]
 
 
 def _resolve(user):
@@ -96,6 +97,7 @@ def test_other_aerosol_models_vs_reference(gpu_pkg, name, monkeypatch):
     g = np.load(os.path.join(GOLD, "aer_model_%s.npz" % name))
     user = _resolve(json.loads(str(g["user_json"])))
     p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
+    rs.validate_parameters(p)          # also fills the reference-wavelength indices of a single-wavelength run (SOS_PROC.F:1704)
     nb_mie = int(user["-ANG.Aer.NbGauss"])
     got = A.aerosols(p, user["-SOS_Main.Wa"], 0.1, nb_mie, 2 * nb_mie, at_waref=user["-SOS_Main.Wa"] == user["-AER.Waref"])
     for k in ("alpha", "beta", "gamma", "zeta"):
