@@ -428,6 +428,15 @@ PROC_CKD_CASES = {
                                                           "-ANG.Aer.NbGauss": 40, "-AP.AbsProfile.Type": 1, "-AP.H2O": 2.5,
                                                           "-AP.O3": 310.0, "-AER.AOTref": 0.2, "-AER.Waref": 1.0e4 / 15925.0,
                                                           "-AER.Tronca": 1, "-SURF.Type": 2, "-SURF.Alb": 0.0, "-SURF.Ind": 1.34}),
+    # BASELINE config 5 at one wavenumber: all-gas CKD band (H2O x O2, 25 bins, mid-latitude summer with user CO2 / CH4),
+    # LND aerosol, Roujean BRDF + Maignan BPDF, polar view, Trans + Flux files
+    "cfg5_ckd_maignan_25bins": dict(_CKDBASE, **_LND, **{"-SOS_Main.Wa": 1.0e4 / 15925.0, "-ANG.Rad.NbGauss": 16, "-ANG.Aer.NbGauss": 20,
+                                                        "-AP.AbsProfile.Type": 2, "-AP.CO2": 420.0, "-AP.CH4": 1.9, "-AER.AOTref": 0.15,
+                                                        "-AER.Waref": 1.0e4 / 15925.0, "-AER.Tronca": 1, "-SURF.Type": 7,
+                                                        "-SURF.Alb": 0.02, "-SURF.Ind": 1.5, "-SURF.Maignan.C": 4.0,
+                                                        "-SURF.Roujean.K0": 0.2, "-SURF.Roujean.K1": 0.03, "-SURF.Roujean.K2": 0.25,
+                                                        "-SOS.View": 2, "-SOS.View.Dphi": 120, "-SOS.Trans": "SOS_Transm.txt",
+                                                        "-SOS.Flux": "Flux.txt"}),
     # the single-profile shortcut -SOS.AbsModeCKD 2 on the O2-A band, US standard atmosphere, output at 3 km
     "ckd_o2a_mode2": dict(_CKDBASE, **{"-SOS_Main.Wa": 0.762, "-ANG.Rad.NbGauss": 16, "-AP.AbsProfile.Type": 6, "-AER.AOTref": 0.0,
                                        "-SURF.Type": 0, "-SURF.Alb": 0.05, "-SOS.AbsModeCKD": 2, "-SOS.OutputAlt": 3.0,

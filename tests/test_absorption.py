@@ -17,7 +17,7 @@ import cases
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ABS_CASES = ["o2a_mls", "h2o_o2_trop_user", "h2o_o2_subarctic", "o2a_us62_nopsurf"]
-CKD_CASES = ["ckd_o2a_5bins", "ckd_h2o_o2_25bins_flatsea", "ckd_o2a_mode2"]
+CKD_CASES = ["ckd_o2a_5bins", "ckd_h2o_o2_25bins_flatsea", "ckd_o2a_mode2", "cfg5_ckd_maignan_25bins"]
 
 
 @pytest.fixture()
@@ -157,7 +157,9 @@ def test_sos_proc_ckd_vs_reference(gpu_pkg, fic, name, tmp_path):
         user["-AER.UserFile"] = f
         coef = 0.0
     out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
-    cases.compare_proc_outputs(rs, out, g, coef_tronca=coef)
+    # land surfaces: REAL*4 reflection matrices with rare last-bit differences enter linearly (cf. tests/test_land.py)
+    rtol = 2e-7 if int(user.get("-SURF.Type", 0)) >= 3 else 1e-9
+    cases.compare_proc_outputs(rs, out, g, coef_tronca=coef, rtol=rtol)
     # SOS_Result.bin: the reference appends one all-zero record per aggregated bin after the first (SOS_AGGREGATE.F:357-413)
     from oracle import ref_ctypes as R
     got = np.array(R.read_fortran_records(str(tmp_path / "SOS" / "SOS_Result.bin")))
@@ -167,7 +169,7 @@ def test_sos_proc_ckd_vs_reference(gpu_pkg, fic, name, tmp_path):
     for r in (got, ref):
         r[:, [n, w + n, 2 * w + n]] = 0.0             # slot jj = 0 is never initialised by the reference
     scale = np.abs(ref[:, 2 * w:]).max()
-    assert np.all(np.abs(got - ref[:len(got)]) <= 1e-9 * np.abs(ref[:len(got)]) + 1e-12 * scale)
+    assert np.all(np.abs(got - ref[:len(got)]) <= rtol * np.abs(ref[:len(got)]) + max(1e-12, 1e-3 * rtol) * scale)
     for key in ("file_trans", "file_flux"):
         if key in g.files:
             fname = user["-SOS.Trans"] if key == "file_trans" else user["-SOS.Flux"]
