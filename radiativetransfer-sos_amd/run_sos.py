@@ -518,6 +518,21 @@ def write_surface_file(path, rsurf):
             f.write(m + payload + m)
 
 
+def _dist_rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def _shard_range(nb, rank, world):
+    from .dist import shard_range
+    return shard_range(nb, rank, world)
+
+
 def validate_parameters(p):
     """The user-parameter checks of SOS_PROC in the reference's order (SOS_PROC.F:1310-1335, 1540-2475): the first violated
     rule raises SosProcError carrying the reference's error number (`.code`, the label of its message block at
@@ -869,6 +884,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
                      ipolar=int(p["ipolar"]), igmax=igmax, rsurf=rsurf, device=device)
     try:
         # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device, one fused solve, one aggregate
+        band_sharded = False                          # True: every rank holds a slice of the band and the partials are all-reduced
         if not use_gas:
             if iprofil == 1:
                 h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, ha)
@@ -888,7 +904,18 @@ def sos_proc(aer_phase=None, device=0, **kw):
             aik = np.ones(1)
             tabs_flux = np.zeros(_abs.NLEVEL)
         else:
-            tabs = ctx.absorption_profiles(ik, xk, ro_lay)                           # SOS_ABSPROFILE of every bin
+            # Several GPUs (torch.distributed initialised, one process per GPU): the bins of the band are sharded
+            # contiguously over the ranks (dist.shard_range); solve_band's one all-reduce joins them and every rank returns
+            # the same 23 outputs.  A rank may hold no bin at all.  (-SOS.AbsModeCKD 2 has a single bin: not sharded.)
+            rank, world = _dist_rank_world()
+            lo, hi = (0, len(aik)) if (world == 1 or mode_ckd == 2) else _shard_range(len(aik), rank, world)
+            sharded = (hi - lo) != len(aik)
+            band_sharded = world > 1 and mode_ckd != 2
+            tabs_last = None
+            if sharded:
+                tabs_last = ctx.absorption_profiles(ik[-1:], xk, ro_lay)             # TAUABS of the band's last bin (Flux file)
+                ik, aik = ik[lo:hi], aik[lo:hi]
+            tabs = ctx.absorption_profiles(ik, xk, ro_lay) if len(aik) else None     # SOS_ABSPROFILE of every bin of this rank
             if mode_ckd == 2:
                 # one profile from the band-mean transmission of every level (SOS_PROC.F:3609-3676)
                 tb = tabs.cpu().numpy()
@@ -898,21 +925,25 @@ def sos_proc(aer_phase=None, device=0, **kw):
                 tabs = np.maximum(-np.log(trs), 0.0)[None]
                 aik = np.ones(1)
             try:
-                bins = ctx.make_profiles(len(aik), tr, p["hr"], ta, ha, prep["altabs"], tabs, a_tronc=a_tronc, piz=piz,
-                                         piztr=piztr, zout=zout, absprofil=absprofil)
+                if len(aik):
+                    bins = ctx.make_profiles(len(aik), tr, p["hr"], ta, ha, prep["altabs"], tabs, a_tronc=a_tronc, piz=piz,
+                                             piztr=piztr, zout=zout, absprofil=absprofil)
+                else:
+                    bins = dict(nb=0, scal=None)
             except Exception as e:
                 raise SosProcError("SOS_PROFILE: %s" % e, ier=-1)
-            tabs_flux = (tabs[-1].cpu().numpy() if hasattr(tabs, "cpu") else np.asarray(tabs)[-1])   # TAUABS of the last bin
+            tl = tabs_last if sharded else tabs
+            tabs_flux = (tl[-1].cpu().numpy() if hasattr(tl, "cpu") else np.asarray(tl)[-1])   # TAUABS of the last bin
         tdifmug = None
         want_trans = str(p["fictrans"]).strip() != "NO_OUTPUT"
-        if want_trans:                                                               # SOS.F:600-635
+        if want_trans and bins["nb"]:                                                # SOS.F:600-635
             tdifmus_b, tdifmug = ctx.diffuse_transmissions(bins)
             sc = bins["scal"] if hasattr(bins["scal"], "clone") else torch.from_numpy(np.asarray(bins["scal"])).to(ctx.device)
             sc = sc.clone()
             sc[:, 0] = tdifmus_b
             bins["scal"] = sc
         try:
-            rec, fin = ctx.solve_band(bins, aik, tdifmug=tdifmug)
+            rec, fin = ctx.solve_band(bins, aik, tdifmug=tdifmug, reduce=band_sharded)
         except SosBinError as e:
             raise SosProcError(str(e), ier=-1)
         nf = int(fin["n_orders"][0])
@@ -922,7 +953,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
                                                   igli, p["wind"] if igli else 0.0, land=land)
         emoins, eplus = float(fin["emoins"][0]), float(fin["eplus"][0])
         resbin = str(p["ficsos_res_bin"]).strip()
-        resroot = str(p["resroot"]).strip()
+        resroot = str(p["resroot"]).strip() if _dist_rank_world()[0] == 0 else ""      # files: rank 0 only
         if resroot:                                   # SOS_PROC.F:1342-1500: results under RESROOT/SOS
             os.makedirs(os.path.join(resroot, "SOS"), exist_ok=True)
             # the two angle files SOS_ANGLES always writes (SOS_ANGLES.F:367-376, 494-506)

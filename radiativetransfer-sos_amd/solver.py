@@ -190,19 +190,21 @@ class SosContext:
                    "sosgpu_profile")
         return dict(nb=nb, lp=lp, perm=None, nt=nt, iborm=iborm, prof=prof, jout=jout, zz=zz, zprof=zprof, scal=scal)
 
-    def solve_band(self, bins, aik, seg=None, group=None, tdifmug=None):
+    def solve_band(self, bins, aik, seg=None, group=None, tdifmug=None, reduce=True):
         """The whole per-wavelength bin loop of SOS_PROC (SOS_PROC.F:3459-3594) for bins already on the device
         (upload_bins / make_profiles): fused SOS_OS of every bin, AIK-weighted SOS_AGGREGATE, and -- when
         torch.distributed is initialised with more than one rank -- the one all-reduce that joins the ranks' bin
         slices.  aik[nb]: this rank's normalised weights (in the order of `bins`; apply bins["perm"] first when the
         upload was cost-sorted).  A rank may hold no bin at all (nb = 0): it contributes the neutral element.
+        reduce=False: this rank holds the whole band (a replica, not a shard) -- no collective.
         Raises SosBinError (the reference's IER = -1) on every rank when any bin of the band is malformed.
         Returns (rec[nseg][smax+1][3][W] device tensor, scalars dict of dist.finish_scalars)."""
         from . import dist as _dist
         out = self.solve(bins) if bins["nb"] else None
         rec, scal = self.aggregate(out, aik, seg=seg, scal=bins.get("scal"), tdifmug=tdifmug)
-        buf = _dist.all_reduce_partial(_dist.pack_partial(rec, scal), scal.shape[1], group=group)
-        rec, scal = _dist.unpack_partial(buf, rec.shape)
+        if reduce:
+            buf = _dist.all_reduce_partial(_dist.pack_partial(rec, scal), scal.shape[1], group=group)
+            rec, scal = _dist.unpack_partial(buf, rec.shape)
         fin = _dist.finish_scalars(scal)
         if (fin["min_orders"] < 0).any():
             raise SosBinError("SOS_OS: %d band(s) hold a malformed bin (NT outside 1..CTE_OS_NT or IBORM out of range)"

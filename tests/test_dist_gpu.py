@@ -43,3 +43,23 @@ def test_sharded_band_rccl_two_gpus(tmp_path):
         pytest.skip("needs two GPUs")
     r = _run(2, "nccl", tmp_path, 9)
     assert r["rec_err"] < 1e-13 and r["tdifmug_err"] < 1e-13 and r["n_orders"][0] == r["n_orders"][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world", [("ckd_h2o_o2_25bins_flatsea", 3), ("ckd_o2a_5bins", 4), ("cfg2_lnd_lambert", 2)])
+def test_sos_proc_sharded(tmp_path, case, world):
+    """The drop-in under torch.distributed: run_sos.sos_proc shards the CKD bins of the band over the ranks (BASELINE config 3:
+    25 bins over 3 ranks; 5 bins over 4 ranks with the Trans + Flux files written by rank 0 -- at most 4 ranks: the GPU box allows
+    six processes on the card, this one included), joins them with
+    the one all-reduce and returns the reference's outputs on every rank; a single-bin run (no gas absorption) is a replica on
+    every rank and must not be reduced."""
+    out = str(tmp_path / "res.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "tests", "dist_proc_worker.py"), "--case", case, "--out", out]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    r = json.load(open(out))
+    assert r["world"] == world and len(set(r["sums"])) == 1, r["sums"]
+    assert "SOS_Result.bin" in r["files"] and "SOS_UsedAngles.txt" in r["files"]
