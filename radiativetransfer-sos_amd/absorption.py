@@ -16,6 +16,7 @@ bin, used by the single-profile mode -SOS.AbsModeCKD 2 bookkeeping and by tests.
 Data: CKD coefficient files and SO2-NO2 are read from $SOS_ABS_ROOT/fic like the reference does (GETENV, SOS_SUB_TRS.F:616);
 the six predefined atmospheres come from data/afgl_atmospheres.npz (scripts/make_afgl_tables.py).  REAL*4 literals of the
 Fortran are widened exactly as the compiler does (`_F`)."""
+import functools
 import os
 
 import numpy as np
@@ -104,11 +105,22 @@ def ckd_file_name(nabs, nu, nustep):
 
 def read_ckd_coeff(nabs, nu, nustep, root=None):
     """READ_CKD_COEFF for gas nabs (1-based): dict(numax, numin, tab_temp, tab_pres, tab_conc (H2O), nexp[nwa],
-    ai[nwa][5], ki[nwa][5][NP][NT] (H2O: [nwa][5][NC][NP][NT])).  List-directed reads: one record per READ."""
+    ai[nwa][5], ki[nwa][5][NP][NT] (H2O: [nwa][5][NC][NP][NT])).  List-directed reads: one record per READ.
+    A file holds 50 spectral intervals (the H2O ones take 0.25 s to parse): parsed files are kept (the last 32, keyed by
+    path, size and modification time), so a hyperspectral loop re-reads nothing while it stays inside a file."""
     if nustep not in (1, 5, 10):
         raise AbsorptionError("The required spectral resolution is not supported : %g cm-1" % nustep)
     rel, numax_f, numin_f = ckd_file_name(nabs, nu, nustep)
     path = os.path.join(root or fic_root(), rel)
+    try:
+        st = os.stat(path)
+    except OSError:
+        raise AbsorptionError("Error while opening the file of CKD coefficients\nFile :%s" % path)
+    return _read_ckd_file(path, nabs, nustep, numax_f, numin_f, st.st_size, st.st_mtime_ns)
+
+
+@functools.lru_cache(maxsize=32)
+def _read_ckd_file(path, nabs, nustep, numax_f, numin_f, _size, _mtime):
     try:
         with open(path) as f:
             lines = f.read().splitlines()
