@@ -437,6 +437,10 @@ PROC_CKD_CASES = {
                                                         "-SURF.Roujean.K0": 0.2, "-SURF.Roujean.K1": 0.03, "-SURF.Roujean.K2": 0.25,
                                                         "-SOS.View": 2, "-SOS.View.Dphi": 120, "-SOS.Trans": "SOS_Transm.txt",
                                                         "-SOS.Flux": "Flux.txt"}),
+    # user-supplied gas / temperature profile (-AP.AbsProfile.Type 0), H2O x O2 band, Rayleigh only, Lambert, user H2O column
+    "ckd_userprofile_25bins": dict(_CKDBASE, **{"-SOS_Main.Wa": 1.0e4 / 15925.0, "-ANG.Rad.NbGauss": 12, "-AP.AbsProfile.Type": 0,
+                                                "-AP.AbsProfile.UserFile": "@GOLDEN/user_abs_profile.txt", "-AP.H2O": 1.8,
+                                                "-AER.AOTref": 0.0, "-SURF.Type": 0, "-SURF.Alb": 0.3, "-SOS.Flux": "Flux.txt"}),
     # the single-profile shortcut -SOS.AbsModeCKD 2 on the O2-A band, US standard atmosphere, output at 3 km
     "ckd_o2a_mode2": dict(_CKDBASE, **{"-SOS_Main.Wa": 0.762, "-ANG.Rad.NbGauss": 16, "-AP.AbsProfile.Type": 6, "-AER.AOTref": 0.0,
                                        "-SURF.Type": 0, "-SURF.Alb": 0.05, "-SOS.AbsModeCKD": 2, "-SOS.OutputAlt": 3.0,
@@ -456,7 +460,7 @@ def gen_sos_proc_ckd(only=None):
             continue
         tmp = tempfile.mkdtemp(prefix="sosproc_")
         try:
-            u = dict(user)
+            u = resolve_user(user)
             u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF",
                       "-SOS_Main.Log": "NO_LOG_FILE", "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE", "-SOS.Log": "NO_LOG_FILE"})
             u.setdefault("-SOS.Flux", "NO_OUTPUT")

@@ -17,7 +17,7 @@ import cases
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ABS_CASES = ["o2a_mls", "h2o_o2_trop_user", "h2o_o2_subarctic", "o2a_us62_nopsurf"]
-CKD_CASES = ["ckd_o2a_5bins", "ckd_h2o_o2_25bins_flatsea", "ckd_o2a_mode2", "cfg5_ckd_maignan_25bins"]
+CKD_CASES = ["ckd_o2a_5bins", "ckd_h2o_o2_25bins_flatsea", "ckd_o2a_mode2", "cfg5_ckd_maignan_25bins", "ckd_userprofile_25bins"]
 
 
 @pytest.fixture()
@@ -147,7 +147,8 @@ def test_sos_proc_ckd_vs_reference(gpu_pkg, fic, name, tmp_path):
     -SOS.Flux files number for number."""
     rs = gpu_pkg.run_sos
     g = np.load(os.path.join(GOLD, "sos_proc_%s.npz" % name))
-    user = json.loads(str(g["user_json"]))
+    user = {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v)
+            for k, v in json.loads(str(g["user_json"])).items()}
     user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS_Main.ResRoot": str(tmp_path)})
     user.setdefault("-SOS.Flux", "NO_OUTPUT")
     coef = None
