@@ -30,6 +30,9 @@
 #define SOS_STREAM_NT 2
 #endif
 namespace {
+#ifndef SOS_STREAM_TOP_BARRIER
+#define SOS_STREAM_TOP_BARRIER 0   // 1: workgroup barrier between the store pass of a chunk and the staging of the next one
+#endif
 #ifndef SOS_STREAM_PREFETCH
 #define SOS_STREAM_PREFETCH 0      // 1: request chunk c+1 from inside the store pass of chunk c.  Measured 3.4 % SLOWER (21.4 k vs
                                    // 22.1 k bins/s, profiles/r02_stream_experiments.txt): the per-unit address arithmetic of the
@@ -345,7 +348,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                 // l0-1 .. l0+30, level vectors of levels l0-1 .. l0+38.  In the passes of order >= 2 every chunk but the first
                 // was already requested by the store pass of the chunk before it (below).
                 if (O1 || !SOS_STREAM_PREFETCH || chk == 0) {
-                    __syncthreads();              // the previous chunk has left LDS
+                    // No barrier here: the only readers of the chunk buffer after the barrier that precedes the store pass are
+                    // the store pass's own reads, and a 16-byte unit is stored and re-requested by the SAME thread (identical
+                    // unit mapping in glds_copy and in the store loop); the attenuation / level-vector copies have no reader
+                    // left.  The barrier after the staging wait below is the one every wave passes before anything is used.
+                    if (SOS_STREAM_TOP_BARRIER) __syncthreads();
                     if (!O1) glds_copy<NTH, SOS_STREAM_NT>(fld + (size_t)l0 * FS, cbuf, COLS * FS / 2, t);
                     glds_copy<NTH, 0>(att + (size_t)l0 * NS, catt, COLS * NS / 2, t);
                     stage_vec(l0);
