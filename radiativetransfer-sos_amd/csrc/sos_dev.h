@@ -183,7 +183,11 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
             // PRE: the buffer already holds X^A = X+ + X- where X+ used to be and X^B = X+ - X- where X- used to be (combined
             // once per step for all four waves instead of by every wave for itself: 8 sums per k-pair and wave less)
             for (int ct = 0; ct < CT; ct++) {
+#ifdef SOS_EXP_NOADD                                       // timing experiment only (wrong physics): the contraction without its sums
+                if (true) { ba[ct] = b.xp[ct]; bb[ct] = b.xm[ct]; }
+#else
                 if (PRE) { ba[ct] = b.xp[ct]; bb[ct] = b.xm[ct]; }
+#endif
                 else { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
             }
 #pragma unroll
