@@ -138,3 +138,32 @@ def test_angle_and_aerosol_text_files_match_the_reference(pkg, tmp_path):
     assert lines(open(tmp_path / "lum.txt").read()) == lines(d["files"]["SOS_UsedAngles.txt"])
     assert lines(open(tmp_path / "mie.txt").read()) == lines(d["files"]["Aer_UsedAngles.txt"])
     assert lines(open(tmp_path / "aer.txt").read()) == lines(d["files"]["Aerosols.txt"])
+
+
+def test_ascii_result_files_layout(pkg, tmp_path):
+    """SOS_Up.txt / SOS_Down.txt (gen_sos_output, restated from binding/run_sos.py:196-317 by reading -- parity unpinned: the
+    reference script imports its f2py extension, which cannot be built here).  Layout checks: fixed-azimuth view = the
+    phi + 180 half plane first (negated zenith angles, descending), then the phi half plane; polar view = one block of NBLUM
+    rows per azimuth, ceil(360 / dphi) blocks; numbers in the %13.6e / %7.2f columns of the reference's format strings."""
+    rs = pkg.run_sos
+    nbl = 5
+    rng = np.random.default_rng(3)
+    t = lambda: rng.uniform(0.01, 1.0, (361, 81))
+    vza = np.zeros(81); vza[:nbl] = [5., 20., 40., 60., 80.]
+    phi = np.zeros(361); phi[:5] = [0., 80., 160., 240., 320.]
+    arrs = [t() for _ in range(7)]
+    rs.gen_sos_output(str(tmp_path), 1, 1, -1.0, nbl, -999, phi, vza, *arrs)
+    lines = open(tmp_path / "SOS_Up.txt").read().splitlines()
+    data = [ln for ln in lines if not ln.startswith("#")]
+    assert len(data) == 2 * nbl and lines[0].startswith("#UPWARD RADIANCE FIELD")
+    z = [float(ln.split()[0]) for ln in data]
+    assert z == [-80., -60., -40., -20., -5., 5., 20., 40., 60., 80.]
+    assert abs(float(data[0].split()[2]) - arrs[1][0, nbl - 1]) <= 5e-7 * arrs[1][0, nbl - 1]       # I of the phi + 180 plane
+    assert abs(float(data[nbl].split()[2]) - arrs[1][1, 0]) <= 5e-7 * arrs[1][1, 0]                 # I of the phi plane
+    assert len(data[0]) == len("  %7.2f %7.2f  %13.6e  %13.6e  %13.6e  %7.2f %7.2f %13.6e" % ((1.0,) * 8))
+    rs.gen_sos_output(str(tmp_path), 2, 2, 2.5, nbl, 80, phi, vza, *arrs)
+    lines = open(tmp_path / "SOS_Down.txt").read().splitlines()
+    data = [ln for ln in lines if not ln.startswith("#")]
+    assert len(data) == 5 * nbl and lines[0].startswith("#DOWNWARD RADIANCE FIELD")
+    assert [float(ln.split()[0]) for ln in data[::nbl]] == [0., 80., 160., 240., 320.]
+    assert any("2.5" in ln and "altitude" in ln for ln in lines)
