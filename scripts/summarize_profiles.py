@@ -28,28 +28,35 @@ def rows(db, q):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r02"
-    bins = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 4096
+    bins = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 32768      # bench.py's default batch
     nt = int(sys.argv[sys.argv.index("--nt") + 1]) if "--nt" in sys.argv else 30
     src = os.path.join(ROOT, "gpurun_out", "prof", tag)
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
 
-    st = rows(os.path.join(src, "stats", "stats_results.db"),
-              "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc")
+    q = "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc"
+    st = rows(os.path.join(src, "stats", "stats_results.db"), q)
+    if os.path.exists(os.path.join(src, "stats_r", "stats_r_results.db")):        # the realistic-mix leg (k_sos_stream)
+        st = sorted(st + [r for r in rows(os.path.join(src, "stats_r", "stats_r_results.db"), q) if "k_sos_stream" in r[0] or "k_profile" in r[0]],
+                    key=lambda r: -r[2])
     tot = sum(r[2] for r in st)
     with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu   (durations in ns)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mix  (k_sos_os, 32768 bins per launch)\n")
+        f.write("#                                and ... bench.py --steps 3 --warmup 1 --no-cpu --workload realistic --bins 4096  (k_sos_stream, k_profile); durations in ns\n")
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "average_ns", "min_ns", "max_ns", "percent"])
         for r in st:
             w.writerow([r[0], r[1], r[2], "%.1f" % r[3], r[4], r[5], "%.2f" % (100.0 * r[2] / tot)])
     print("kernel stats:", st[0][0][:60], "avg %.3f ms over %d calls" % (st[0][3] / 1e6, st[0][1]))
 
-    summary = dict(tag=tag, bins_per_gpu=bins, nt=nt, command="python3 bench.py --steps 3 --warmup 1 --no-cpu")
+    summary = dict(tag=tag, bins_per_gpu=bins, nt=nt, command="python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mix")
     lines = []
     for pas, counter, factor in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
-        db = os.path.join(src, pas, "%s_results.db" % pas)
-        r = rows(db, "select name, count(*), avg(counter_value) from pmc_events where counter_name = '%s' group by name order by avg(counter_value) desc" % counter)
+        qq = "select name, count(*), avg(counter_value) from pmc_events where counter_name = '%s' group by name order by avg(counter_value) desc" % counter
+        r = rows(os.path.join(src, pas, "%s_results.db" % pas), qq)
+        dbr = os.path.join(src, pas + "_r", "%s_r_results.db" % pas)
+        if os.path.exists(dbr):
+            r = r + [x for x in rows(dbr, qq) if "k_sos_stream" in x[0]]
         for name, n, mean in r:
             lines.append([name, counter, n, "%.3f" % mean, "%.4e" % (factor * mean * 1024.0)])
             if "k_sos_os" in name:
@@ -70,7 +77,8 @@ def main():
     print("hbm:", summary)
     if "k_sos_stream_fetch_bytes" in summary and "k_sos_stream_write_bytes" in summary:
         # the realistic-mix leg of the same command (bench.py run_realistic): read by bench.pmc_traffic("_realistic")
-        mix = dict(tag=tag, bins_per_gpu=bins, command=summary["command"], workload="realistic_mix",
+        mix = dict(tag=tag, bins_per_gpu=4096, command="python3 bench.py --steps 3 --warmup 1 --no-cpu --workload realistic --bins 4096",
+                   workload="realistic_mix",
                    k_sos_os_bytes_per_launch=summary["k_sos_stream_fetch_bytes"] + summary["k_sos_stream_write_bytes"],
                    fetch_bytes=summary["k_sos_stream_fetch_bytes"], write_bytes=summary["k_sos_stream_write_bytes"])
         with open(os.path.join(out, "%s_pmc_hbm_realistic.json" % tag), "w") as f:
