@@ -312,7 +312,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;
     // variant: field in LDS, or (NT too large) field in a per-bin HBM scratch, launched in sub-batches so that
-    // the scratch stays below ~8 GiB
+    // the scratch stays below its budget
     int nw, rtw, ct, big;
     size_t lds;
     const int nt_max = lp - 1;          // lp - 1 bounds every NT of the batch (the host pads the level axis to lp)
@@ -322,7 +322,10 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     const int lpb = sos_round_up(lp, 32);
     const size_t per_bin = big ? sos_stream_scratch_doubles(cx->d.n, lpb) : 0;
     if (big) {
-        const size_t cap = ((size_t)8 << 30) / sizeof(double);
+        // scratch budget: 64 GiB of the 288 GB (a launch covers ~40 000 bins at 608 levels; SOSGPU_SCRATCH_GIB overrides it)
+        size_t gib = 64;
+        if (const char *e = getenv("SOSGPU_SCRATCH_GIB")) { const long v = atol(e); if (v > 0) gib = (size_t)v; }
+        const size_t cap = (gib << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
         const size_t need = per_bin * per_launch;
         if (need > cx->scratch_doubles) {
