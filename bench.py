@@ -38,11 +38,12 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X dense FP64 MFMA peak (MI355X_MICROARCH.md); s
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md
 
 
-def build_workload(S, nb, nt, seed, g):
+def build_workload(S, nb, nt, seed, g, part=None):
+    """The seeded band of nb bins; part = (lo, hi): only this rank's slice of it is built."""
     mu, w, n0 = S.gauss_angles(40, 35.0)
     os_nb = 80
     al, be, ga, ze = S.hg_phase(os_nb, g)
-    bins = S.ckd_bins(nb, nt, seed=seed)
+    bins = S.ckd_bins(nb, nt, seed=seed, part=part)
     h, x, y, iborm = S.rescale_profile(bins["h"], bins["xdel"], bins["ydel"], 0.0, 0.95, 0.95, os_nb)
     return dict(mu=mu, w=w, n0=n0, os_nb=os_nb, coefs=(al, be, ga, ze), h=h, xdel=x, ydel=y, zprof=bins["zprof"],
                 aik=bins["aik"], iborm=iborm)
@@ -240,12 +241,12 @@ def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup
     Fourier-order counts)."""
     # every rank owns `nbins` bins of one global band of world*nbins bins (weights normalised globally)
     nb_tot = nbins * world
-    wl = build_workload(S, nb_tot, args.nt, 1234, args.g)
     lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
+    wl = build_workload(S, nb_tot, args.nt, 1234, args.g, part=(lo, hi))
     al, be, ga, ze = wl["coefs"]
     cx = pkg.SosContext(wl["mu"], wl["w"], wl["n0"], al, be, ga, ze, iborm_max=wl["iborm"], ro=0.1, device=dev)
-    bins = cx.upload_bins(wl["h"][lo:hi], wl["xdel"][lo:hi], wl["ydel"][lo:hi], order=None if args.no_sort else "cost")
-    aik_h = wl["aik"][lo:hi].copy()
+    bins = cx.upload_bins(wl["h"], wl["xdel"], wl["ydel"], order=None if args.no_sort else "cost")
+    aik_h = wl["aik"].copy()
     if bins["perm"] is not None:
         aik_h = aik_h[bins["perm"]]
     aik = torch.from_numpy(aik_h).to(cx.device)

@@ -91,13 +91,16 @@ def profile(nt, tau_r=0.0948, tau_a=0.3, k_abs=0.0, hr=8.0, ha=2.0, hg=4.0, ztoa
     return out
 
 
-def ckd_bins(nb, nt, seed=1234, tau_r=0.0948, tau_a=0.3, kmin=1e-3, kmax=30.0):
+def ckd_bins(nb, nt, seed=1234, tau_r=0.0948, tau_a=0.3, kmin=1e-3, kmax=30.0, part=None):
     """nb per-bin profiles differing by the gas absorption (k_b log-uniform in [kmin,kmax]) and
     Dirichlet(1) weights AIK normalised to 1 (SOS_PROC.F:3481-3487).  Returns dict of arrays
-    h/xdel/ydel/zprof [nb][nt+1], aik [nb], k_abs [nb]."""
+    h/xdel/ydel/zprof [nb][nt+1], aik [nb], k_abs [nb].  part = (lo, hi): only that slice of the nb bins is built (the
+    random draws are those of the whole band, so a rank's slice equals the same rows of the full call)."""
     rng = np.random.default_rng(seed)
     k = np.exp(rng.uniform(np.log(kmin), np.log(kmax), nb))
     aik = rng.dirichlet(np.ones(nb)) if nb > 1 else np.ones(1)
+    if part is not None:
+        k, aik = k[part[0]:part[1]], aik[part[0]:part[1]]
     H, X, Y, Z = profile(nt, tau_r, tau_a, k)
     return dict(h=H, xdel=X, ydel=Y, zprof=Z, aik=aik, k_abs=k)
 
