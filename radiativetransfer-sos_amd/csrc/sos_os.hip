@@ -435,7 +435,15 @@ static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipSt
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the dynamic-LDS limit of a kernel is set once per device and size (the call costs tens of microseconds: with few bins per
+    // wavelength the host launch path is what bounds a hyperspectral loop, scripts/spectrum_bench.py)
+    static size_t configured[16] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[dev] < lds)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && dev >= 0 && dev < 16) configured[dev] = lds;
+    }
     if (e == hipSuccess) {
         kern<<<bn.nb, 64 * NW, lds, st>>>(cx, bn);
         e = hipGetLastError();

@@ -675,7 +675,15 @@ static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_
 {
     auto kern = k_sos_stream<NW, RTWH, ZO, SURF>;
     const size_t lds = stream_lds_bytes(NW, RTWH);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the dynamic-LDS limit of a kernel is set once per device and size (the call costs tens of microseconds: with few bins per
+    // wavelength the host launch path is what bounds a hyperspectral loop, scripts/spectrum_bench.py)
+    static size_t configured[16] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[dev] < lds)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && dev >= 0 && dev < 16) configured[dev] = lds;
+    }
     if (e == hipSuccess) {
         kern<<<bn.nb, 64 * NW, lds, st>>>(cx, bn);
         e = hipGetLastError();

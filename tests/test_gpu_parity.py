@@ -228,3 +228,30 @@ def test_diffuse_transmissions_vs_oracle(gpu_pkg, oracle):
             assert abs(tdifmug[b, j - 1] - r["emoins"]) <= 1e-9 * abs(r["emoins"]) + 1e-300, (b, j)
         assert tdifmus[b] == tdifmug[b, n0 - 1]
     cx.close()
+
+
+@pytest.mark.gpu
+def test_solve_many_overlapping_wavelengths(gpu_pkg):
+    """solver.solve_many: several wavelengths (contexts) with a few bins each on separate HIP streams give exactly the bands of
+    the one-at-a-time calls (same kernels, same data: bit-identical)."""
+    import torch
+    S = gpu_pkg.synth
+    mu, w, n0 = S.gauss_angles(24, 35.0)
+    items, ref = [], []
+    for i, g in enumerate((0.6, 0.7, 0.8, 0.75, 0.65)):
+        al, be, ga, ze = S.hg_phase(48, g)
+        b = S.ckd_bins(6, 30, seed=50 + i)
+        h, x, y, iborm = S.rescale_profile(b["h"], b["xdel"], b["ydel"], 0.0, 0.95, 0.95, 48)
+        cx = gpu_pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=iborm, ro=0.05 * (i + 1))
+        bins = cx.upload_bins(h, x, y)
+        aik = torch.from_numpy(b["aik"]).to(cx.device)
+        items.append((cx, bins, aik))
+        rec, scal = cx.aggregate(cx.solve(bins), aik)
+        torch.cuda.synchronize()
+        ref.append((rec.clone(), scal.clone()))
+    got = gpu_pkg.solver.solve_many(items, n_streams=3)
+    torch.cuda.synchronize()
+    for (r, s), (r0, s0) in zip(got, ref):
+        assert torch.equal(r, r0) and torch.equal(s, s0)
+    for cx, _, _ in items:
+        cx.close()
