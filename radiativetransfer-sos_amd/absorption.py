@@ -211,7 +211,8 @@ def _splint(x, y, d2, xv):
         raise AbsorptionError("ERROR for SPLINT interpolation")
     a = (x[khi] - xv) / h
     b = (xv - x[klo]) / h
-    return a * y[klo] + b * y[khi] + ((a ** 3 - a) * d2[klo] + (b ** 3 - b) * d2[khi]) * (h ** 2) / 6.
+    # A**3, H**2 with integer exponents are products in the compiled Fortran
+    return a * y[klo] + b * y[khi] + ((a * a * a - a) * d2[klo] + (b * b * b - b) * d2[khi]) * (h * h) / 6.
 
 
 def interpo_splint(xin, yin, xv):
@@ -318,15 +319,129 @@ def prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprof
                 tab_conc=gas[0]["tab_conc"])
 
 
+def _spline_rows(x, y, dy1, dyn):
+    """_spline for many tables at once: y, result [n_rows][n]; x [n] common abscissae; the end slopes per row.  Same statements
+    in the same order, element by element (IEEE double arithmetic: identical to the scalar routine)."""
+    n = len(x)
+    d2 = np.zeros_like(y)
+    u = np.zeros_like(y)
+    big = dy1 > _F(.99E30)
+    d2[:, 0] = np.where(big, 0., -0.5)
+    u[:, 0] = np.where(big, 0., (3. / (x[1] - x[0])) * ((y[:, 1] - y[:, 0]) / (x[1] - x[0]) - dy1))
+    for k in range(1, n - 1):
+        sig = (x[k] - x[k - 1]) / (x[k + 1] - x[k - 1])
+        p = sig * d2[:, k - 1] + 2.
+        d2[:, k] = (sig - 1.) / p
+        u[:, k] = (6. * ((y[:, k + 1] - y[:, k]) / (x[k + 1] - x[k]) - (y[:, k] - y[:, k - 1]) / (x[k] - x[k - 1])) / (x[k + 1] - x[k - 1])
+                   - sig * u[:, k - 1]) / p
+    bign = dyn > _F(.99E30)
+    qn = np.where(bign, 0., 0.5)
+    un = np.where(bign, 0., (3. / (x[n - 1] - x[n - 2])) * (dyn - (y[:, n - 1] - y[:, n - 2]) / (x[n - 1] - x[n - 2])))
+    d2[:, n - 1] = (un - qn * u[:, n - 2]) / (qn * d2[:, n - 2] + 1.)
+    for k in range(n - 2, -1, -1):
+        d2[:, k] = d2[:, k] * d2[:, k + 1] + u[:, k]
+    return d2
+
+
+def _bracket(tab, v):
+    """Index i of the scalar search `while tab[i] <= v and i < n-1: i += 1; i -= 1` for every element of v."""
+    i = np.searchsorted(tab, v, side="right")            # first index with tab[i] > v
+    i = np.minimum(i, len(tab) - 1)
+    return i - 1
+
+
+def coeff_abs_ckd_rows(nabs, ki, tab_pres, tab_temp, tab_conc, prs, tmp, conc):
+    """coeff_abs_ckd for arrays of layers (prs, tmp, conc [L]): returns (xk[L], prs, tmp, conc) with the clamped values, element
+    by element what the scalar routine returns (tests/test_absorption.py compares the two)."""
+    prs, tmp, conc = prs.copy(), tmp.copy(), conc.copy()
+    tmp = np.minimum(np.maximum(tmp, tab_temp[0]), tab_temp[-1])
+    low = prs <= tab_pres[0]                                  # no absorption above the table: state left as it is (but TMP)
+    act = ~low
+    xk = np.zeros(len(prs))
+    if not act.any():
+        return xk, prs, tmp, conc
+    pa = np.minimum(prs[act], tab_pres[-1])
+    ta = tmp[act]
+    ca = conc[act]
+    if tab_conc is not None:
+        ca = np.minimum(np.maximum(ca, tab_conc[0]), tab_conc[-1])
+    ip = _bracket(tab_pres, pa)
+    if nabs == 1:
+        ic = _bracket(tab_conc, ca)
+        k0, k1 = ki[ic], ki[ic + 1]                            # [La][NP][NT]
+        c0, c1 = tab_conc[ic][:, None, None], tab_conc[ic + 1][:, None, None]
+        xkh = ((k1 - k0) / (c1 - c0)) * (ca[:, None, None] - c1) + k1
+        rows = np.arange(len(pa))
+        a0, a1 = xkh[rows, ip], xkh[rows, ip + 1]
+    else:
+        a0, a1 = ki[ip], ki[ip + 1]                            # [La][NT]
+    p0, p1 = tab_pres[ip][:, None], tab_pres[ip + 1][:, None]
+    xki = ((a1 - a0) / (p1 - p0)) * (pa[:, None] - p1) + a1    # [La][NT]
+    x = tab_temp
+    dy1 = (xki[:, 1] - xki[:, 0]) / (x[1] - x[0])
+    dyn = (xki[:, -1] - xki[:, -2]) / (x[-1] - x[-2])
+    d2 = _spline_rows(x, xki, dy1, dyn)
+    # _splint: bisection with (KHI+KLO)/2 on 1-based indices == the bracket of the ascending table for an in-range abscissa
+    nt = len(x)
+    klo = np.zeros(len(ta), dtype=np.int64); khi = np.full(len(ta), nt - 1, dtype=np.int64)
+    while np.any(khi - klo > 1):
+        k = (khi + klo + 2) // 2 - 1
+        go = khi - klo > 1
+        up = x[k] > ta
+        khi = np.where(go & up, k, khi)
+        klo = np.where(go & ~up, k, klo)
+    rows = np.arange(len(ta))
+    h = x[khi] - x[klo]
+    if np.any(h == 0.):
+        raise AbsorptionError("ERROR for SPLINT interpolation")
+    aa = (x[khi] - ta) / h
+    bb = (ta - x[klo]) / h
+    val = aa * xki[rows, klo] + bb * xki[rows, khi] + ((aa * aa * aa - aa) * d2[rows, klo] + (bb * bb * bb - bb) * d2[rows, khi]) * (h * h) / 6.
+    neg = val < 0.
+    if neg.any():
+        it = _bracket(x, ta)
+        lin = ((xki[rows, it + 1] - xki[rows, it]) / (x[it + 1] - x[it])) * (ta - x[it + 1]) + xki[rows, it + 1]
+        val = np.where(neg, lin, val)
+        if np.any(val < 0.):
+            raise AbsorptionError("COEFF_ABS_CKD : ERROR_923 : Calculations give ki < 0 : uncorrect value!")
+    xk[act] = val
+    prs[act], conc[act] = pa, ca
+    return xk, prs, tmp, conc
+
+
 def layer_tables(prep):
     """XK(gas, term, layer) RO(gas, layer) of SOS_ABSPROFILE.F:325-353 for every exponential term of every gas:
-    returns (xk [8][5][49], ro [8][49]) with layer index J-1, J = 1 the TOP layer (the reference's loop order)."""
+    returns (xk [8][5][49], ro [8][49]) with layer index J-1, J = 1 the TOP layer (the reference's loop order).
+    All 49 layers of a (term, gas) pair are interpolated together (coeff_abs_ckd_rows); the clamped pressure / temperature /
+    water-vapour state is carried from gas to gas per layer exactly as the reference carries it."""
+    u = prep["userprofil"]
+    nl = NLEVEL
+    xk = np.zeros((NBABS, CKD_NAI_MAX, nl - 1))
+    j = np.arange(1, nl)
+    lo, hi = nl - j - 1, nl - j                       # USERPROFIL(NLEVEL-J), USERPROFIL(NLEVEL-J+1), 0-based rows
+    for term in range(CKD_NAI_MAX):
+        prs = (u[lo, 1] + u[hi, 1]) / 2.
+        tmp = (u[lo, 2] + u[hi, 2]) / 2.
+        conc = (u[lo, 3] + u[hi, 3]) / 2.
+        conc = conc * 1.e-06
+        for k in range(NBABS):
+            if term >= prep["nexp"][k]:
+                continue
+            xk[k, term], prs, tmp, conc = coeff_abs_ckd_rows(k + 1, prep["ki"][k][term], prep["tab_pres"], prep["tab_temp"],
+                                                             prep["tab_conc"], prs, tmp, conc)
+    ro = prep["ro"][:, nl - j - 1].copy()             # RO(K, NLEVEL-J)
+    return xk, ro
+
+
+def layer_tables_scalar(prep):
+    """The layer-by-layer form of layer_tables (one coeff_abs_ckd call per layer, term and gas): kept as the statement-for-
+    statement restatement the vectorised form is tested against."""
     u = prep["userprofil"]
     nl = NLEVEL
     xk = np.zeros((NBABS, CKD_NAI_MAX, nl - 1))
     ro = np.zeros((NBABS, nl - 1))
     for j in range(1, nl):
-        lo, hi = nl - j - 1, nl - j                  # USERPROFIL(NLEVEL-J), USERPROFIL(NLEVEL-J+1), 0-based rows
+        lo, hi = nl - j - 1, nl - j
         for term in range(CKD_NAI_MAX):
             prs = (u[lo, 1] + u[hi, 1]) / 2.
             tmp = (u[lo, 2] + u[hi, 2]) / 2.
@@ -337,7 +452,7 @@ def layer_tables(prep):
                     continue
                 xk[k, term, j - 1], prs, tmp, conc = coeff_abs_ckd(k + 1, prep["ki"][k][term], prep["tab_pres"], prep["tab_temp"],
                                                                    prep["tab_conc"], prs, tmp, conc)
-        ro[:, j - 1] = prep["ro"][:, nl - j - 1]      # RO(K, NLEVEL-J)
+        ro[:, j - 1] = prep["ro"][:, nl - j - 1]
     return xk, ro
 
 

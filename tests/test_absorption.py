@@ -177,3 +177,14 @@ def test_sos_proc_ckd_vs_reference(gpu_pkg, fic, name, tmp_path):
             mine, theirs = _floats(open(str(tmp_path / "SOS" / fname)).read()), _floats(str(g[key]))
             assert mine.shape == theirs.shape, key
             assert np.all(np.abs(mine - theirs) <= 1.001e-4 + 1e-9 * np.abs(theirs)), (key, np.abs(mine - theirs).max())
+
+
+def test_vectorised_layer_tables_equal_the_scalar_restatement(pkg, fic):
+    """layer_tables interpolates the 49 layers of a (term, gas) pair together; it must reproduce, bit for bit, the layer-by-layer
+    form that follows COEFF_ABS_CKD statement for statement (clamps carried from gas to gas included)."""
+    A = pkg.absorption
+    for wa, ap, h2o in ((0.762, 2, -999.), (1.0e4 / 15925.0, 1, 2.5), (1.0e4 / 15925.0, 6, -999.)):
+        prep = A.prepa_absprofile(wa, 10.0, 1013.0, h2o, -999., -999., -999., ap)
+        xv, rv = A.layer_tables(prep)
+        xs, rs_ = A.layer_tables_scalar(prep)
+        assert np.array_equal(xv, xs) and np.array_equal(rv, rs_) and (xs != 0).sum() > 100
