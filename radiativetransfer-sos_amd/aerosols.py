@@ -14,6 +14,7 @@ functions, 5 user mixture of log-normal / Junge modes.
 
 REAL*4 variables and literals of the Fortran are kept REAL*4 (`np.float32`) where they decide a value."""
 import ctypes as C
+import functools
 import math
 import os
 
@@ -43,6 +44,7 @@ def _round_sig(x, sig):
     return out
 
 
+@functools.lru_cache(maxsize=16)
 def mie_angles(nb_gauss):
     """Mie angle set without user angles: positive Gauss nodes of the 2 nb_gauss-point rule, ascending, as re-read from
     Aer_UsedAngles.txt (D21.14).  Returns xmu[-N:N], xhr[-N:N] as arrays of 2N+1 (index j + N; entry N unused = 0)."""
@@ -56,6 +58,7 @@ def mie_angles(nb_gauss):
     return xmu, xhr
 
 
+@functools.lru_cache(maxsize=64)
 def alpha_grid(alphao, alphaf):
     """Size parameters SOS_MIE steps through (ALPHA = ALPHA + PAS with the REAL*4 step literals, SOS_MIE.F:437-443,707)."""
     out = []
@@ -133,8 +136,95 @@ def granu(rec, igranu, v1, v2, v3, wa):
     return kmat1 / somme_nr, kmat2 / somme_nr, somme_nr, p11, p12, p33
 
 
+def _seq_sum(a):
+    """Left-to-right sum along the last axis (np.cumsum accumulates sequentially, np.sum pairwise): the order of the Fortran loops."""
+    return np.cumsum(a, axis=-1)[..., -1]
+
+
 def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
     """SOS_DECOMPO_LEGENDRE: forward-peak truncation (log-linear extrapolation of P11 beyond acos(0.94), slope taken between
+    acos(0.8) and acos(0.94)) and the expansions alpha, beta, gamma, zeta (0:os_nb), normalised by beta_0.
+    Returns dict(alpha, beta, gamma, zeta, beta22, delta33, coef_tronca, itronc).
+    Vectorised over the angles and orders with the reference's summation order kept (sequential sums): bit-identical to
+    decompo_legendre_loops (tests/test_aerosols.py)."""
+    w = len(xmu)
+    n = (w - 1) // 2
+    J = lambda j: j + n
+    ttt = p11_in.copy()
+    kk = np.arange(os_nb + 1)
+    sel = np.array([j for j in range(w) if j != n])                 # J = -N..N without 0, ascending
+    xr = xmu[sel]
+    # Legendre polynomials P_k(xr): PL(K+1) = ((2K+1) X PL(K) - K PL(K-1)) / (K+1)
+    pl = np.zeros((os_nb + 2, len(sel)))
+    pl[0] = 1.
+    plm = np.zeros(len(sel))
+    for k in range(os_nb + 1):
+        pl[k + 1] = ((2 * k + 1.) * xr * pl[k] - k * (pl[k - 1] if k else plm)) / (k + 1.)
+    while True:
+        p11 = ttt.copy()
+        if itronc:
+            k1 = next((j - 1 for j in range(1, n + 1) if xmu[J(j)] > MU1_TRONCA), None)
+            k2 = next((j - 1 for j in range(1, n + 1) if xmu[J(j)] > MU2_TRONCA), None)
+            if k1 is None or k2 is None:
+                raise AerosolError("truncation angles outside the Mie angle set")
+            aa = (math.log10(p11[J(k2)]) - math.log10(p11[J(k1)])) / (math.acos(xmu[J(k2)]) - math.acos(xmu[J(k1)]))
+            x1, x2 = math.log10(p11[J(k2)]), math.acos(xmu[J(k2)])
+            for j in range(k2 + 1, n + 1):
+                p11[J(j)] = 10 ** (x1 + aa * (math.acos(xmu[J(j)]) - x2))
+        x = p11[sel] * xhr[sel]
+        beta11 = _seq_sum(x[None, :] * pl[:os_nb + 1])
+        beta11 = (2 * kk + 1) * beta11 * .5
+        coef = 2 * (1 - beta11[0]) if itronc else 0.0
+        if itronc and coef < SEUIL_TRONCA:
+            itronc = 0                    # truncation too small to matter: start again without it (SOS_AEROSOLS.F:4195-4214)
+            continue
+        break
+    # generalised functions POL(K), K >= 2
+    pol = np.zeros((os_nb + 2, len(sel)))
+    pol[2] = 3. * (1. - xr ** 2) / 2. / math.sqrt(6.0)
+    for k in range(2, os_nb + 1):
+        d = (2. * k + 1.) / math.sqrt(1. * (k + 3.) * (k - 1.))
+        e = math.sqrt(1. * (k + 2.) * (k - 2.)) / (2. * k + 1.)
+        pol[k + 1] = d * (xr * pol[k] - e * pol[k - 1])
+    xxx = xhr[sel] * p12[sel] * p11[sel] / ttt[sel]
+    xb = xhr[sel] * p22[sel] * (p11[sel] / ttt[sel])
+    xx = xhr[sel] * p33[sel] * p11[sel] / ttt[sel]
+    gamma12 = np.zeros(os_nb + 1)
+    gamma12[2:] = _seq_sum(xxx[None, :] * pol[2:os_nb + 1])
+    beta22 = _seq_sum(xb[None, :] * pl[:os_nb + 1])
+    delta33 = _seq_sum(xx[None, :] * pl[:os_nb + 1])
+    beta22 = beta22 * (2. * kk + 1.) * .5
+    delta33 = delta33 * (2. * kk + 1.) * .5
+    gamma12 = gamma12 * (2. * kk + 1.) * .5
+    alp, zeta = np.zeros(os_nb + 1), np.zeros(os_nb + 1)
+    f = np.float32
+    for i in range(2, os_nb + 1):               # CO1, CO2, X2 are REAL*4 expressions (as in SOS_MAT_FRESNEL)
+        co1 = float(f(4) * (f(2 * i) + f(1.)) / f(i) / (f(i) - f(1.)) / (f(i) + f(1.)) / (f(i) + f(2.)))
+        co2 = float(f(i) * (f(i) - f(1.)) / ((f(i) + f(1.)) * (f(i) + f(2.))))
+        co3 = co2 * delta33[i]
+        co2 = co2 * beta22[i]
+        nn, mm = int(i * .5), int((i - 1) * .5)
+        fi1 = (f(i) - f(1.)) * (f(i) - f(1.))
+        s1 = s2 = s3 = s4 = 0.
+        if nn >= 1:
+            jn = np.arange(1, nn + 1)
+            x2 = (fi1 - f(3.) * ((2 * jn).astype(np.float32) - f(1.)) * (i - jn).astype(np.float32)).astype(np.float64)
+            s1 = float(_seq_sum(x2 * beta22[i - 2 * jn]))
+            s2 = float(_seq_sum(x2 * delta33[i - 2 * jn]))
+        jm = np.arange(0, mm + 1)
+        x2 = (fi1 - f(3.) * jm.astype(np.float32) * ((2 * i - 2 * jm).astype(np.float32) - f(1.))).astype(np.float64)
+        s3 = float(_seq_sum(x2 * beta22[i - 2 * jm - 1]))
+        s4 = float(_seq_sum(x2 * delta33[i - 2 * jm - 1]))
+        zeta[i] = co3 - co1 * (s2 - s3)
+        alp[i] = co2 - co1 * (s1 - s4)
+    z1 = beta11[0]
+    return dict(alpha=alp / z1, beta=beta11 / z1, gamma=gamma12 / z1, zeta=zeta / z1, beta22=beta22 / z1, delta33=delta33 / z1,
+                coef_tronca=float(coef), itronc=itronc)
+
+
+def decompo_legendre_loops(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
+    """The statement-for-statement form of decompo_legendre (scalar loops), kept as what the vectorised form is tested against.
+    SOS_DECOMPO_LEGENDRE: forward-peak truncation (log-linear extrapolation of P11 beyond acos(0.94), slope taken between
     acos(0.8) and acos(0.94)) and the expansions alpha, beta, gamma, zeta (0:os_nb), normalised by beta_0.
     Returns dict(alpha, beta, gamma, zeta, beta22, delta33, coef_tronca, itronc)."""
     w = len(xmu)

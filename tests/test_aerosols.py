@@ -121,3 +121,21 @@ def test_sos_proc_with_its_own_aerosol_model(gpu_pkg):
     user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
     out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
     cases.compare_proc_outputs(rs, out, g, rtol=5e-6)
+
+
+def test_vectorised_decompo_equals_the_loop_restatement(pkg):
+    """decompo_legendre (sequential sums over whole arrays) == decompo_legendre_loops (the statement-for-statement loops), bit
+    for bit, with and without truncation, spherical and non-spherical (P22 != P11) input."""
+    A = pkg.aerosols
+    rng = np.random.default_rng(1)
+    for nbm, osnb, itr, g in ((24, 48, 1, 0.6), (24, 48, 0, 0.85), (5, 10, 1, 0.7), (40, 80, 1, 0.8)):
+        xmu, xhr = A.mie_angles(nbm)
+        l = np.arange(3 * osnb)
+        p11 = np.maximum(np.polynomial.legendre.legval(xmu, (2 * l + 1) * g ** l), 1e-6)
+        p12 = 0.1 * p11 * (1 - xmu ** 2) * rng.uniform(0.5, 1.5, len(xmu))
+        p22, p33 = p11 * rng.uniform(0.9, 1.0, len(xmu)), 0.9 * p11 * xmu
+        a = A.decompo_legendre(itr, xmu, xhr, osnb, p11, p12, p22, p33)
+        b = A.decompo_legendre_loops(itr, xmu, xhr, osnb, p11, p12, p22, p33)
+        for k in ("alpha", "beta", "gamma", "zeta", "beta22", "delta33"):
+            assert np.array_equal(a[k], b[k]), (nbm, itr, k)
+        assert a["coef_tronca"] == b["coef_tronca"] and a["itronc"] == b["itronc"]
