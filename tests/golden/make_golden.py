@@ -355,6 +355,103 @@ VALIDATION_CASES = [
 ]
 
 
+def random_proc_case(rng, gas=False):
+    """One random, valid keyword set for SOS_PROC (small angle sets; gas = True: a multi-bin CKD band at one of the two
+    wavenumbers the trimmed fixture tables cover)."""
+    nb_lum = int(rng.choice([8, 12, 16, 24]))
+    nb_mie = int(rng.choice([10, 16, 24]))
+    u = {"-SOS_Main.Wa": float(rng.choice([0.443, 0.55, 0.67, 0.865, 1.02])), "-ANG.Rad.NbGauss": nb_lum, "-ANG.Aer.NbGauss": nb_mie,
+         "-ANG.Thetas": float(rng.choice([0.0, 12.5, 30.0, 47.3, 63.0, 75.0])), "-AP.Psurf": float(rng.choice([1013.0, 850.0, 700.0])),
+         "-AP.HR": 8.0, "-AP.AerHS.HA": float(rng.choice([1.0, 2.0, 3.5])), "-AP.AbsProfile.Type": 7,
+         "-AER.AOTref": float(rng.choice([0.0, 0.05, 0.2, 0.6, 1.2])), "-SOS.IGmax": int(rng.choice([2, 5, 100])),
+         "-SOS.Ipolar": int(rng.choice([1, 1, 1, 0])), "-AER.Tronca": int(rng.choice([1, 1, 0]))}
+    u["-AER.Waref"] = u["-SOS_Main.Wa"]
+    if u["-AER.AOTref"] > 0:
+        u.update({"-AER.Model": 0, "-AER.MMD.SDtype": 1, "-AER.MMD.LNDradius": float(rng.choice([0.08, 0.15, 0.3, 0.5])),
+                  "-AER.MMD.LNDvar": float(rng.choice([0.4, 0.6, 0.8])), "-AER.MMD.MRwa": float(rng.choice([1.35, 1.45, 1.53])),
+                  "-AER.MMD.MIwa": float(rng.choice([0.0, -0.003, -0.02]))})
+        if rng.random() < 0.3:
+            u.update({"-AP.AerProfile.Type": 2, "-AP.AerLayer.Zmin": float(rng.choice([0.0, 1.0])), "-AP.AerLayer.Zmax": float(rng.choice([2.0, 4.0]))})
+    surf = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7]))
+    u["-SURF.Type"] = surf
+    u["-SURF.Alb"] = float(rng.choice([0.0, 0.05, 0.3])) if surf in (0, 1, 2) else float(rng.choice([0.0, 0.02]))
+    if surf in (1, 2, 4, 5, 7):
+        u["-SURF.Ind"] = 1.34 if surf in (1, 2) else 1.5
+    if surf == 1:
+        u["-SURF.Glitter.Wind"] = float(rng.choice([2.0, 5.0, 10.0]))
+    if surf >= 3:
+        u.update({"-SURF.Roujean.K0": float(rng.choice([0.1, 0.25])), "-SURF.Roujean.K1": float(rng.choice([0.0, 0.04])),
+                  "-SURF.Roujean.K2": float(rng.choice([0.1, 0.3]))})
+    if surf == 7:
+        u["-SURF.Maignan.C"] = float(rng.choice([3.0, 6.0]))
+    if rng.random() < 0.5:
+        u.update({"-SOS.View": 1, "-SOS.View.Phi": float(rng.choice([0.0, 35.0, 90.0, 170.0]))})
+    else:
+        u.update({"-SOS.View": 2, "-SOS.View.Dphi": int(rng.choice([45, 72, 120]))})
+    if rng.random() < 0.4:
+        u["-SOS.OutputAlt"] = float(rng.choice([0.5, 2.0, 7.0]))
+    if rng.random() < 0.3:
+        u["-ANG.Rad.UserAngFile"] = "@GOLDEN/user_angles.txt"
+    if rng.random() < 0.3:
+        u["-AP.MOT"] = float(rng.choice([0.05, 0.15, 0.3]))
+        if not gas:
+            u.pop("-AP.Psurf")
+    if gas:
+        u["-SOS_Main.Wa"] = u["-AER.Waref"] = float(rng.choice([0.762, 1.0e4 / 15925.0]))
+        u.update({"-AP.AbsProfile.Type": int(rng.choice([1, 2, 3, 4, 5, 6])), "-AP.SpectralResol": 10,
+                  "-SOS.AbsModeCKD": int(rng.choice([1, 1, 2]))})
+        u.pop("-AP.AerProfile.Type", None); u.pop("-AP.AerLayer.Zmin", None); u.pop("-AP.AerLayer.Zmax", None)
+        u["-AP.Psurf"] = float(rng.choice([1013.0, 900.0]))
+        for key, vals in (("-AP.H2O", [0.5, 3.0]), ("-AP.O3", [250.0, 400.0]), ("-AP.CO2", [380.0, 450.0]), ("-AP.CH4", [1.7, 2.1])):
+            if rng.random() < 0.4:
+                u[key] = float(rng.choice(vals))
+    return u
+
+
+def gen_sos_proc_random(n=12, seed=2024, gas=False, first=0):
+    """Seeded random keyword sets through the reference's SOS_PROC (fuzz at the drop-in boundary): the fixture keeps the keyword
+    set, the Aerosols.txt content the reference produced and the 23 outputs."""
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    rng = np.random.default_rng(seed)
+    os.environ["SOS_ABS_ROOT"] = "/root/reference"
+    done = 0
+    while done < n:
+        user = random_proc_case(rng, gas)
+        tmp = tempfile.mkdtemp(prefix="sosproc_")
+        try:
+            u = resolve_user(user)
+            u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF", "-SOS_Main.Log": "NO_LOG_FILE",
+                      "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE", "-SOS.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+            p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), u), trace=False)
+            try:
+                rs.validate_parameters(dict(p))
+            except rs.SosProcError:
+                continue
+            out = R.sos_proc(list(p.items()))
+            if not np.isfinite(out[5]).all() or np.abs(out[5]).max() == 0.0:
+                continue                                   # the reference refused or failed this combination
+            os_nb = 2 * int(user["-ANG.Aer.NbGauss"])
+            d = {"user_json": json.dumps(user)}
+            if user["-AER.AOTref"] != 0.0:
+                aer = rs.read_aerosols_file(os.path.join(tmp, "SOS", "Aerosols.txt"), os_nb)
+                head = open(os.path.join(tmp, "SOS", "Aerosols.txt")).read().splitlines()[:2]
+                d["kmat"] = np.array([float(h.split(":")[1]) for h in head])
+                for k, v in aer.items():
+                    d["aer_" + k] = np.asarray(v)
+            for nm, v in zip(rs.OUTPUT_NAMES, out):
+                d[nm] = np.asarray(v)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        np.savez_compressed(os.path.join(HERE, "sos_proc_rand_%02d.npz" % (first + done)), **d)
+        print("sos_proc_rand", first + done, {k: v for k, v in user.items() if k.startswith(("-SURF.Type", "-AER.AOT", "-SOS.View", "-SOS.Out", "-AP.Aer", "-SOS.Ip", "-SOS.IG"))},
+              "i_up[0,:2]", out[5][0, :2])
+        done += 1
+
+
 def gen_angle_files():
     """The text files SOS_ANGLES / SOS_AEROSOLS write for a tiny case with user angles in both angle sets
     (SOS_UsedAngles.txt, Aer_UsedAngles.txt, and the Aerosols.txt of an aerosol-free run)."""
@@ -635,6 +732,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "proc_random":
+        if len(sys.argv) > 3 and sys.argv[3] == "gas":
+            gen_sos_proc_random(int(sys.argv[2]), seed=7, gas=True, first=12)
+        else:
+            gen_sos_proc_random(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "angle_files":
         gen_angle_files()

@@ -167,3 +167,30 @@ def test_ascii_result_files_layout(pkg, tmp_path):
     assert len(data) == 5 * nbl and lines[0].startswith("#DOWNWARD RADIANCE FIELD")
     assert [float(ln.split()[0]) for ln in data[::nbl]] == [0., 80., 160., 240., 320.]
     assert any("2.5" in ln and "altitude" in ln for ln in lines)
+
+
+RANDOM_CASES = sorted(f[len("sos_proc_"):-4] for f in os.listdir(GOLD) if f.startswith("sos_proc_rand_"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RANDOM_CASES)
+def test_sos_proc_random_keyword_sets_vs_reference(gpu_pkg, name, tmp_path, monkeypatch):
+    """Fuzz at the drop-in boundary: seeded random keyword sets (surfaces 0-5 and 7, exponential and layer aerosol profiles,
+    scalar and polarised runs, IGMAX limits, output altitudes, user viewing angles, fixed-azimuth and polar views; rand_12..19:
+    multi-bin CKD bands with random atmospheres, gas amounts and both CKD modes) through the
+    compiled reference's SOS_PROC (make_golden.py proc_random) and through run_sos.sos_proc on the GPU.  Aerosols enter through
+    the reference's own Aerosols.txt (-AER.UserFile), so the comparison is at 1e-9 (2e-7 over land: REAL*4 surface matrices)."""
+    rs = gpu_pkg.run_sos
+    monkeypatch.setenv("SOS_ABS_ROOT", GOLD)               # trimmed CKD tables of the two fixture wavenumbers
+    g = np.load(os.path.join(GOLD, "sos_proc_%s.npz" % name))
+    user = {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v)
+            for k, v in json.loads(str(g["user_json"])).items()}
+    user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+    coef = None
+    if user["-AER.AOTref"] != 0.0:
+        f = str(tmp_path / "Aerosols_user.txt")
+        rs.write_aerosols_file(f, {k: g["aer_" + k] for k in ("alpha", "beta", "gamma", "zeta", "a_tronc", "piztr", "piz")}, *g["kmat"])
+        user["-AER.UserFile"] = f
+        coef = 0.0
+    out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
+    cases.compare_proc_outputs(rs, out, g, coef_tronca=coef, rtol=2e-7 if int(user["-SURF.Type"]) >= 3 else 1e-9)
