@@ -237,6 +237,10 @@ AER_MODEL_CASES = {
                                                   "-AER.BMD.FM.MRwaref": 1.45, "-AER.BMD.FM.MIwaref": -0.005, "-AER.BMD.FM.SDradius": 0.09,
                                                   "-AER.BMD.FM.SDvar": 0.5, "-ANG.Rad.UserAngFile": "@GOLDEN/user_angles.txt",
                                                   "-SOS.View": 2, "-SOS.View.Dphi": 90}),
+    # more Legendre / Fourier terms than the default: OS_NB = 2 x 70 = 140 (CTE_OS_NB_MAX = 200), 32 radiance angles, coarse mode
+    "lnd_osnb140": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-ANG.Aer.NbGauss": 70, "-ANG.Rad.NbGauss": 32, "-AER.Model": 0,
+                                     "-AER.MMD.SDtype": 1, "-AER.MMD.LNDradius": 0.8, "-AER.MMD.LNDvar": 0.6, "-AER.MMD.MRwa": 1.40,
+                                     "-AER.MMD.MIwa": -0.001, "-AER.AOTref": 0.5}),
     # few scattering orders allowed (IGMAX reached everywhere), LND, no truncation, Roujean + Breon land surface
     "lnd_igmax3_breon": dict(_MODBASE, **{"-SOS_Main.Wa": 0.550, "-AER.Model": 0, "-AER.MMD.SDtype": 1, "-AER.MMD.LNDradius": 0.2,
                                           "-AER.MMD.LNDvar": 0.5, "-AER.MMD.MRwa": 1.5, "-AER.MMD.MIwa": -0.01, "-AER.Tronca": 0,

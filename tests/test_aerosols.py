@@ -60,7 +60,7 @@ def test_aerosol_model_vs_reference_aerosols_file(gpu_pkg, name):
 
 
 MODEL_CASES = ["wmo_continental", "wmo_user_865", "sf_maritime_rh70", "sf_urban_rh0", "ext_phase_fct", "mixture_3modes_865",
-               "junge_2wl_nopolar_glitter", "bilnd_vc1_2wl_userangles", "lnd_igmax3_breon"]
+               "junge_2wl_nopolar_glitter", "bilnd_vc1_2wl_userangles", "lnd_igmax3_breon", "lnd_osnb140"]
 
 
 def _resolve(user):
