@@ -236,13 +236,16 @@ class SosContext:
                 cx.close()
         return tdifmus, tdifmug
 
-    def alloc_outputs(self, nb):
+    def alloc_outputs(self, nb, zero=True):
+        """Output buffers of solve().  zero=True: rec is zero-initialised (the kernel only writes the orders a bin runs,
+        sosgpu.h); zero=False: plain allocations -- for callers that read the records through norders only (aggregate does),
+        it saves four fill kernels per call (they matter when many small launches share the GPU, solve_many)."""
         d = self.device
-        # rec is zero-initialised once here: the kernel only writes the orders a bin runs (sosgpu.h)
-        return dict(rec=torch.zeros((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),
-                    norders=torch.zeros(nb, dtype=torch.int32, device=d),
-                    iglast=torch.zeros((nb, self.smax + 1), dtype=torch.int32, device=d),
-                    flux=torch.zeros((nb, 2), dtype=torch.float64, device=d))
+        mk = torch.zeros if zero else torch.empty
+        return dict(rec=mk((nb, self.smax + 1, 3, self.w), dtype=torch.float64, device=d),
+                    norders=mk(nb, dtype=torch.int32, device=d),
+                    iglast=mk((nb, self.smax + 1), dtype=torch.int32, device=d),
+                    flux=mk((nb, 2), dtype=torch.float64, device=d))
 
     def solve(self, bins, out=None):
         """Run the fused SOS_OS kernel on a batch of bins already resident in HBM (upload_bins)."""
@@ -349,7 +352,7 @@ def solve_many(items, n_streams=16):
     res = []
     for i, (cx, bins, aik) in enumerate(items):
         with torch.cuda.stream(streams[i % len(streams)]):
-            out = cx.solve(bins)
+            out = cx.solve(bins, cx.alloc_outputs(bins["nb"], zero=False))
             res.append(cx.aggregate(out, aik, scal=bins.get("scal")))
     for st in streams:
         cur.wait_stream(st)
