@@ -106,6 +106,24 @@ int  sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const 
                      const double *d_prof, const int32_t *d_jout, const double *d_zz,
                      double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream);
 
+/* Many wavelengths in ONE launch (hyperspectral runs, BASELINE config 5: each wavelength has only 5-100 CKD bins, a fraction
+ * of the 512 workgroups the chip hosts).  The reference runs SOS_PROC once per wavelength (binding/run_sos.py:640); here the
+ * bin loops SOS_PROC.F:3459-3594 of nctx wavelengths are concatenated and every bin carries the index of its wavelength.
+ *   sosgpu_ctx_table   copies the device-side description of nctx contexts (sosgpu_ctx_table_entry_bytes() each) into the
+ *                      caller's device buffer d_table; synchronous.  All contexts must live on one device and agree in
+ *                      N, iborm_max and IMAT_SURF (E_ARG otherwise).  The table refers to the contexts' operator tables: it
+ *                      stays valid until one of them is destroyed or has sosgpu_set_surface_matrices called again.
+ *   sosgpu_os_solve_multi   sosgpu_os_solve with d_ctx_of_bin[nb] (int32, 0..nctx-1): bin b is solved with the operators of
+ *                      table entry d_ctx_of_bin[b].  `cx` is any context of the table (it provides the variant selection, the
+ *                      streamed variant's scratch and the timing events).  All other arguments as sosgpu_os_solve; feed
+ *                      sosgpu_aggregate with one segment per wavelength. */
+size_t sosgpu_ctx_table_entry_bytes(void);
+int  sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table);
+int  sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, int nb, int lp,
+                           const int32_t *d_nt, const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout,
+                           const double *d_zz, double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux,
+                           void *stream);
+
 /* Replaces SOS_AGGREGATE (SOS_AGGREGATE.F:372-488) for nseg independent wavelengths/bands at once:
  * segment g covers bins seg[g]..seg[g+1]-1 of d_rec; seg[0] = 0, seg[nseg] = nb.  One big band (nseg = 1,
  * nb > 128) is reduced in chunks of 64 bins (deterministic; the strict serial bin order of the reference is kept for

@@ -300,9 +300,10 @@ extern "C" int sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out)
     return SOSGPU_OK;
 }
 
-extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const int32_t *d_iborm,
-                               const double *d_prof, const int32_t *d_jout, const double *d_zz,
-                               double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream)
+// sosgpu_os_solve (table == null) and sosgpu_os_solve_multi (per-bin contexts from a device table)
+static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_ctx_of_bin, int nb, int lp, const int32_t *d_nt,
+                         const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout, const double *d_zz,
+                         double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream)
 {
     if (!cx || nb < 0 || lp < 2 || !d_nt || !d_iborm || !d_prof || !d_rec || !d_norders || !d_iglast || !d_flux)
         return SOSGPU_E_ARG;
@@ -348,6 +349,7 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
         bn.norders = d_norders + b0; bn.iglast = d_iglast + (size_t)b0 * S1;
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
+        bn.ctxs = table; bn.ctx_of_bin = table ? d_ctx_of_bin + b0 : nullptr;
         bn.s_begin = 0; bn.s_end = S1;
         if (big) {
             // The streamed kernel can run `opl` Fourier orders of every bin per launch (order-synchronous launches: every
@@ -359,9 +361,11 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
             if (opl <= 0) opl = S1;
             for (int s0 = 0; s0 < S1 && rc == 0; s0 += opl) {
                 bn.s_begin = s0; bn.s_end = std::min(S1, s0 + opl);
-                rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
+                rc = table ? launch_sos_stream_multi(cx->d, bn, nt_max, st, &g_last_hip)
+                           : launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
             }
-        } else rc = launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
+        } else rc = table ? launch_sos_os_multi(cx->d, bn, nt_max, st, &g_last_hip)
+                          : launch_sos_os(cx->d, bn, nt_max, st, &g_last_hip);
         if (rc == -2) return SOSGPU_E_HIP;
         if (rc) return rc;
     }
@@ -369,6 +373,46 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
     cx->timed = true;
     cx->last_stream = st;
     return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const int32_t *d_iborm,
+                               const double *d_prof, const int32_t *d_jout, const double *d_zz,
+                               double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream)
+{
+    return os_solve_impl(cx, nullptr, nullptr, nb, lp, d_nt, d_iborm, d_prof, d_jout, d_zz, d_rec, d_norders, d_iglast, d_flux,
+                         stream);
+}
+
+extern "C" size_t sosgpu_ctx_table_entry_bytes(void) { return sizeof(SosDev); }
+
+extern "C" int sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table)
+{
+    if (!ctxs || nctx < 1 || !d_table || !ctxs[0]) return SOSGPU_E_ARG;
+    const SosDev &a = ctxs[0]->d;
+    std::vector<SosDev> tab((size_t)nctx);
+    for (int i = 0; i < nctx; i++) {
+        if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) return SOSGPU_E_ARG;
+        const SosDev &d = ctxs[i]->d;
+        // what selects the kernel variant and the record layout must agree over the table
+        if (d.n != a.n || d.kh != a.kh || d.ks2h != a.ks2h || d.rtph != a.rtph || d.smax != a.smax ||
+            (d.imat_surf != 0) != (a.imat_surf != 0))
+            return SOSGPU_E_ARG;
+        if (d.imat_surf && !d.mp_gnd) return SOSGPU_E_ARG;
+        tab[i] = d;
+    }
+    HIPCHK(hipSetDevice(ctxs[0]->device));
+    HIPCHK(hipMemcpy(d_table, tab.data(), (size_t)nctx * sizeof(SosDev), hipMemcpyHostToDevice));
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, int nb, int lp,
+                                     const int32_t *d_nt, const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout,
+                                     const double *d_zz, double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux,
+                                     void *stream)
+{
+    if (!d_table || !d_ctx_of_bin) return SOSGPU_E_ARG;
+    return os_solve_impl(cx, static_cast<const SosDev *>(d_table), d_ctx_of_bin, nb, lp, d_nt, d_iborm, d_prof, d_jout, d_zz,
+                         d_rec, d_norders, d_iglast, d_flux, stream);
 }
 
 extern "C" int sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms)

@@ -69,6 +69,21 @@ struct SosBins {
     int s_begin, s_end;          // streamed variant: Fourier orders s_begin <= s < s_end of this launch (order-synchronous
                                  // launches keep the source operator of the order in L2 for every workgroup of an XCD)
     unsigned long long *phase;   // diagnostic builds only (SOS_PROFILE_PHASES): [nb][8] cycle sums per phase
+    // multi-wavelength launches (sos_os_multi.hip / sos_stream_multi.hip): bin b runs with the context ctxs[ctx_of_bin[b]]
+    // of a device-resident context table instead of the kernel argument; null otherwise
+    const SosDev *ctxs;
+    const int32_t *ctx_of_bin;
 };
+
+// The kernels read the wavelength context through `cx`: the by-value kernel argument, or -- SOS_MULTI builds -- the bin's
+// entry of the context table, addressed in the constant address space so that every field stays a scalar load that the
+// compiler may re-issue instead of keeping it in registers (exactly what it does with kernel arguments).
+#ifdef SOS_MULTI
+typedef const __attribute__((address_space(4))) SosDev SosDevK;
+#define SOS_BIND_CTX(cx, arg, bn)                                                                                   \
+    const SosDevK &cx = *(const SosDevK *)(unsigned long long)((bn).ctxs + __builtin_amdgcn_readfirstlane((bn).ctx_of_bin[blockIdx.x]))
+#else
+#define SOS_BIND_CTX(cx, arg, bn) const SosDev &cx = arg
+#endif
 
 static inline int sos_round_up(int a, int b) { return (a + b - 1) / b * b; }

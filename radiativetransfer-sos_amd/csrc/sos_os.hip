@@ -25,6 +25,13 @@
 #include "sos_dev.h"
 #include "kernels.h"
 
+// SOS_MULTI (set by sos_os_multi.hip, which includes this file): the same kernels under other names, reading the wavelength
+// context of each bin from a device table (SosBins::ctxs) -- one launch then covers the bins of many wavelengths.
+#ifdef SOS_MULTI
+#define k_sos_os k_sos_os_multi
+#define launch_sos_os launch_sos_os_multi
+#endif
+
 // NW   : waves per workgroup (4: N <= 42, 8: N <= 85); waves [0,NW/2) hold up-going rows, the rest down-going rows
 // RTWH : row tiles per wave and half system (tile = wave + rt*NW)
 // CT   : column tiles (16 levels each) held in LDS at once
@@ -47,8 +54,9 @@
 #define SOS_MIN_WG(NW, CT) (((NW) == 4) ? 2 : 1)
 #endif
 template <int NW, int RTWH, int CT, bool ZO, bool SURF>
-__global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const SosDev cx, const SosBins bn)
+__global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const SosDev cx_arg, const SosBins bn)
 {
+    SOS_BIND_CTX(cx, cx_arg, bn);
     extern __shared__ double smem[];
     constexpr int NTH = 64 * NW, HW = NW / 2;
     constexpr int COLS = 16 * CT;
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
 // ---------------------------------------------------------------------------------------------
 // variant table
 // ---------------------------------------------------------------------------------------------
+#ifndef SOS_MULTI
 static size_t lds_bytes_for(int nw, int rtw, int ct, bool big)
 {
     const int cols = 16 * ct, fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw);
@@ -427,6 +436,7 @@ int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_by
     if (big) *big = b;
     return 0;
 }
+#endif
 
 template <int NW, int RTWH, int CT, bool ZO, bool SURF>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st, int *hip_err)

@@ -26,6 +26,13 @@
 #include "sos_dev.h"
 #include "kernels.h"
 
+// SOS_MULTI (set by sos_stream_multi.hip, which includes this file): the same kernels under other names, with a per-bin
+// wavelength context read from a device table (see sos_os.hip)
+#ifdef SOS_MULTI
+#define k_sos_stream k_sos_stream_multi
+#define launch_sos_stream launch_sos_stream_multi
+#endif
+
 #ifndef SOS_STREAM_NT
 #define SOS_STREAM_NT 2
 #endif
@@ -108,8 +115,9 @@ __device__ __forceinline__ void glds_copy(const double *g, double *l, int units,
 }
 
 template <int NW, int RTWH, bool ZO, bool SURF>
-__global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void k_sos_stream(const SosDev cx, const SosBins bn)
+__global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void k_sos_stream(const SosDev cx_arg, const SosBins bn)
 {
+    SOS_BIND_CTX(cx, cx_arg, bn);
     extern __shared__ double smem[];
     constexpr int CT = COLS / 16, NTH = 64 * NW, HW = NW / 2;
     constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
@@ -663,12 +671,14 @@ static void stream_shape(int n, int *nw, int *rtw)
     else { *nw = 4; *rtw = kh <= 64 ? 1 : 2; }
 }
 
+#ifndef SOS_MULTI
 size_t sos_stream_scratch_doubles(int n, int lpb)
 {
     int nw, rtw;
     stream_shape(n, &nw, &rtw);
     return stream_scratch_doubles(nw, rtw, lpb);
 }
+#endif
 
 template <int NW, int RTWH, bool ZO, bool SURF>
 static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_t st, int *hip_err)

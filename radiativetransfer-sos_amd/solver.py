@@ -332,6 +332,63 @@ class SosContext:
             pass
 
 
+class ContextTable:
+    """Device-resident table of wavelength contexts (sosgpu_ctx_table) for solve_spectrum: ONE kernel launch then covers the
+    bins of all these wavelengths.  The contexts must agree in N, iborm_max and IMAT_SURF; the table stays valid while they
+    live (rebuild it after closing one or changing its surface matrices)."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        if not self.ctxs:
+            raise ValueError("ContextTable needs at least one context")
+        self.device = self.ctxs[0].device
+        L = capi.lib()
+        n = len(self.ctxs)
+        self.table = torch.empty(n * int(L.sosgpu_ctx_table_entry_bytes()), dtype=torch.uint8, device=self.device)
+        hs = (C.c_void_p * n)(*[cx._h for cx in self.ctxs])
+        capi.check(L.sosgpu_ctx_table(hs, n, _ptr(self.table)), "sosgpu_ctx_table")
+
+
+def concat_bins(bins_list):
+    """Concatenate per-wavelength bin dicts (upload_bins / make_profiles) for solve_spectrum: the level axis is padded to the
+    largest lp.  Returns (bins, ctx_of_bin int32 device tensor, seg int32 device tensor of len(bins_list) + 1)."""
+    d = bins_list[0]["prof"].device
+    lp = max(b["lp"] for b in bins_list)
+    zo = [b["jout"] is not None for b in bins_list]
+    if any(zo) != all(zo):
+        raise ValueError("either every wavelength or none has an output level (zout)")
+    prof = []
+    for b in bins_list:
+        p = b["prof"]
+        if b["lp"] < lp:
+            p = torch.nn.functional.pad(p, (0, lp - b["lp"]))
+        prof.append(p)
+    cat = lambda k: torch.cat([b[k] for b in bins_list])
+    counts = [b["nb"] for b in bins_list]
+    out = dict(nb=int(sum(counts)), lp=lp, perm=None, nt=cat("nt"), iborm=cat("iborm"), prof=torch.cat(prof).contiguous(),
+               jout=cat("jout") if all(zo) else None, zz=cat("zz") if all(zo) else None)
+    if all(b.get("scal") is not None for b in bins_list):
+        out["scal"] = cat("scal")
+    cob = _dev_i32(np.repeat(np.arange(len(bins_list), dtype=np.int32), counts), d)
+    seg = _dev_i32(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), d)
+    return out, cob, seg
+
+
+def solve_spectrum(table, bins, ctx_of_bin, seg, aik, out=None):
+    """The bin loops of MANY wavelengths (one SOS_PROC call each in the reference, binding/run_sos.py:640) as ONE launch of the
+    fused solver plus one segmented SOS_AGGREGATE: bin b runs with the operators of table.ctxs[ctx_of_bin[b]], segment g of
+    `seg` is wavelength g.  bins / ctx_of_bin / seg from concat_bins; aik[nb] device tensor in the same order.
+    Returns (rec[nwavelengths][smax+1][3][W], scal[nwavelengths][10+N]) like SosContext.aggregate; no synchronisation."""
+    cx = table.ctxs[0]
+    if out is None:
+        out = cx.alloc_outputs(bins["nb"], zero=False)
+    capi.check(capi.lib().sosgpu_os_solve_multi(cx._h, _ptr(table.table), _ptr(ctx_of_bin), bins["nb"], bins["lp"],
+                                                _ptr(bins["nt"]), _ptr(bins["iborm"]), _ptr(bins["prof"]),
+                                                _ptr(bins["jout"]), _ptr(bins["zz"]), _ptr(out["rec"]), _ptr(out["norders"]),
+                                                _ptr(out["iglast"]), _ptr(out["flux"]), cx._stream()), "sosgpu_os_solve_multi")
+    return cx.aggregate(out, aik, seg=seg, scal=bins.get("scal"))
+
+
 def solve_many(items, n_streams=16):
     """Hyperspectral shape of the work (BASELINE config 5): MANY wavelengths with FEW CKD bins each.  One wavelength = one
     SosContext (its own source operators); its few bins occupy a fraction of the chip (one workgroup per bin, 512 resident),

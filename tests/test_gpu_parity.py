@@ -255,3 +255,68 @@ def test_solve_many_overlapping_wavelengths(gpu_pkg):
         assert torch.equal(r, r0) and torch.equal(s, s0)
     for cx, _, _ in items:
         cx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nt,surf,zout", [(24, 30, False, False), (41, 45, False, True), (24, 110, False, False),
+                                            (13, 30, True, False), (13, 97, True, True), (49, 28, False, False)])
+def test_solve_spectrum_one_launch_for_many_wavelengths(gpu_pkg, n, nt, surf, zout):
+    """solver.solve_spectrum (sosgpu_os_solve_multi): the bins of several wavelengths -- different phase functions, surface
+    albedos / matrices, solar directions, Fresnel flags and bin counts -- solved by ONE launch with a per-bin context give
+    bit-identical records, order counts, fluxes and bands to the per-wavelength calls (LDS-resident and streamed variants)."""
+    import torch
+    import cases
+    S = gpu_pkg.synth
+    os_nb = 32
+    mu, w, n0 = S.gauss_angles(n - 1, 35.0)
+    assert len(mu) == n
+    ctxs, bl, aiks, ref = [], [], [], []
+    for i, g in enumerate((0.6, 0.8, 0.7, 0.75)):
+        al, be, ga, ze = S.hg_phase(os_nb, g)
+        nbw = 3 + 2 * i
+        b = S.ckd_bins(nbw, nt, seed=70 + i, tau_a=0.1 + 0.1 * i)
+        h, x, y, iborm = S.rescale_profile(b["h"], b["xdel"], b["ydel"], 0.0, 0.95, 0.9 + 0.02 * i, os_nb)
+        kw = dict(ro=0.05 * (i + 1), ifresnel=0 if surf else i % 2)
+        if surf:
+            kw.update(imat_surf=1, rsurf=(1.0 + 0.3 * i) * cases._surf_matrices(n, os_nb, 7 + i))
+        cx = gpu_pkg.SosContext(mu, w, 1 + (n0 - 1 + i) % n, al, be, ga, ze, iborm_max=os_nb, **kw)
+        bins = cx.upload_bins(h, x, y, iborm=np.full(nbw, os_nb if i % 2 else 5, dtype=np.int32),
+                              zout=1.5 if zout else -1.0, zprof=b["zprof"])
+        aik = torch.from_numpy(b["aik"]).to(cx.device)
+        out = cx.solve(bins)
+        rec, scal = cx.aggregate(out, aik)
+        torch.cuda.synchronize()
+        ref.append((out, rec.clone(), scal.clone()))
+        ctxs.append(cx); bl.append(bins); aiks.append(aik)
+    table = gpu_pkg.solver.ContextTable(ctxs)
+    bins, cob, seg = gpu_pkg.solver.concat_bins(bl)
+    out = ctxs[0].alloc_outputs(bins["nb"])
+    rec, scal = gpu_pkg.solver.solve_spectrum(table, bins, cob, seg, torch.cat(aiks), out=out)
+    torch.cuda.synchronize()
+    b0 = 0
+    for i, (o, r0, s0) in enumerate(ref):
+        nbw = o["rec"].shape[0]
+        for k in ("rec", "norders", "iglast", "flux"):
+            assert torch.equal(out[k][b0:b0 + nbw], o[k]), (i, k)
+        assert torch.equal(rec[i], r0[0]) and torch.equal(scal[i], s0[0]), i
+        b0 += nbw
+    assert int(out["norders"].min()) > 0
+    for cx in ctxs:
+        cx.close()
+
+
+@pytest.mark.gpu
+def test_context_table_rejects_mismatched_contexts(gpu_pkg):
+    S = gpu_pkg.synth
+    al, be, ga, ze = S.hg_phase(16, 0.6)
+    mu, w, n0 = S.gauss_angles(8, 35.0)
+    mu2, w2, n02 = S.gauss_angles(12, 35.0)
+    a = gpu_pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=16, ro=0.1)
+    b = gpu_pkg.SosContext(mu2, w2, n02, al, be, ga, ze, iborm_max=16, ro=0.1)
+    c = gpu_pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=8, ro=0.1)
+    for pair in ((a, b), (a, c)):
+        with pytest.raises(gpu_pkg.capi.SosgpuError):
+            gpu_pkg.solver.ContextTable(pair)
+    gpu_pkg.solver.ContextTable((a, a))
+    for cx in (a, b, c):
+        cx.close()
