@@ -328,7 +328,8 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (const char *e = getenv("SOSGPU_SCRATCH_GIB")) { const long v = atol(e); if (v > 0) gib = (size_t)v; }
         const size_t cap = (gib << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
-        const size_t need = per_bin * per_launch;
+        // + the task queues and per-bin order flags of the persistent form (ints, behind the bins' scratch)
+        const size_t need = per_bin * per_launch + (256 + (size_t)per_launch) / 2 + 1;
         if (need > cx->scratch_doubles) {
             HIPCHK(hipDeviceSynchronize());     // a solve of this context may still be in flight on another stream
             if (cx->scratch) (void)hipFree(cx->scratch);
@@ -350,6 +351,8 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
         bn.ctxs = table; bn.ctx_of_bin = table ? d_ctx_of_bin + b0 : nullptr;
+        bn.queue = bn.qflag = nullptr; bn.q_tail = -1;
+        if (const char *e = getenv("SOSGPU_STREAM_QTAIL")) bn.q_tail = atoi(e);
         bn.s_begin = 0; bn.s_end = S1;
         if (big) {
             // The streamed kernel can run `opl` Fourier orders of every bin per launch (order-synchronous launches: every
@@ -359,6 +362,18 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
             int opl = 0;
             if (const char *e = getenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH")) opl = atoi(e);
             if (opl <= 0) opl = S1;
+            // SOSGPU_STREAM_PERSIST=1: ONE persistent launch whose workgroups take (Fourier order, bin) tasks from per-XCD queues,
+            // so that the workgroups of an XCD share the source operators of one or two orders in L2 (sos_stream.hip, PERSIST).
+            // Measured on the realistic mix (profiles/r02_stream_experiments.txt): fabric reads 505 -> 317 GB per launch (the
+            // operator misses are gone), 22.2 k against 22.6 k bins/s -- the kernel is not bound by that traffic, so one
+            // workgroup per bin stays the default.  Launches with a context table always use the default form.
+            int persist = 0;
+            if (const char *e = getenv("SOSGPU_STREAM_PERSIST")) persist = atoi(e);
+            if (persist && !table && opl == S1) {
+                bn.queue = reinterpret_cast<int *>(cx->scratch + per_bin * per_launch);
+                bn.qflag = bn.queue + 256;
+                HIPCHK(hipMemsetAsync(bn.queue, 0, (256 + (size_t)bn.nb) * sizeof(int), st));
+            }
             for (int s0 = 0; s0 < S1 && rc == 0; s0 += opl) {
                 bn.s_begin = s0; bn.s_end = std::min(S1, s0 + opl);
                 rc = table ? launch_sos_stream_multi(cx->d, bn, nt_max, st, &g_last_hip)

@@ -69,6 +69,12 @@ struct SosBins {
     int s_begin, s_end;          // streamed variant: Fourier orders s_begin <= s < s_end of this launch (order-synchronous
                                  // launches keep the source operator of the order in L2 for every workgroup of an XCD)
     unsigned long long *phase;   // diagnostic builds only (SOS_PROFILE_PHASES): [nb][8] cycle sums per phase
+    // persistent, order-scheduled form of the streamed variant (sos_stream.hip, PERSIST), or null: queue[16 q] = task counter
+    // of queue q (one per XCD), queue[16 (8 + q)] = finished bins of queue q; qflag[nb] = Fourier orders completed per bin.
+    // All zero before the launch.
+    int *queue, *qflag;
+    int q_tail;                  // a queue with at most this many unfinished bins hands out whole bins (all remaining orders);
+                                 // < 0: the launcher's default (twice the workgroups per queue)
     // multi-wavelength launches (sos_os_multi.hip / sos_stream_multi.hip): bin b runs with the context ctxs[ctx_of_bin[b]]
     // of a device-resident context table instead of the kernel argument; null otherwise
     const SosDev *ctxs;
@@ -78,12 +84,15 @@ struct SosBins {
 // The kernels read the wavelength context through `cx`: the by-value kernel argument, or -- SOS_MULTI builds -- the bin's
 // entry of the context table, addressed in the constant address space so that every field stays a scalar load that the
 // compiler may re-issue instead of keeping it in registers (exactly what it does with kernel arguments).
-#ifdef SOS_MULTI
 typedef const __attribute__((address_space(4))) SosDev SosDevK;
+typedef const __attribute__((address_space(4))) SosBins SosBinsK;
+#ifdef SOS_MULTI
 #define SOS_BIND_CTX(cx, arg, bn)                                                                                   \
     const SosDevK &cx = *(const SosDevK *)(unsigned long long)((bn).ctxs + __builtin_amdgcn_readfirstlane((bn).ctx_of_bin[blockIdx.x]))
 #else
 #define SOS_BIND_CTX(cx, arg, bn) const SosDev &cx = arg
 #endif
+// offset of the second kernel argument (SosBins) behind the first (SosDev) in the kernarg segment: both 8-byte aligned
+#define SOS_KERNARG_BINS_OFFSET ((sizeof(SosDev) + 7) & ~(size_t)7)
 
 static inline int sos_round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -22,6 +22,7 @@
 // loaded.  Algebraically the reference recurrence X_i = t X_{i+1} + p S_i + w S_{i+1}; rounding differs at 1e-16 of the field.
 // Scratch traffic per scattering order: the field once in and once out (the field-in-HBM variant of round 1 moved it three
 // times, with the B operands and both sweeps latency-bound on global memory).
+#include <algorithm>
 #include <cstdlib>
 #include "sos_dev.h"
 #include "kernels.h"
@@ -114,10 +115,12 @@ __device__ __forceinline__ void glds_copy(const double *g, double *l, int units,
                                          (__attribute__((address_space(3))) void *)(unsigned long)(lb + (unsigned)full * (NTH * 16)), 16, 0, AUX);
 }
 
-template <int NW, int RTWH, bool ZO, bool SURF>
+template <int NW, int RTWH, bool ZO, bool SURF, bool PERSIST>
 __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void k_sos_stream(const SosDev cx_arg, const SosBins bn)
 {
     SOS_BIND_CTX(cx, cx_arg, bn);
+    const auto &cx_kernel = cx;
+    const SosBins &bn_kernel = bn;
     extern __shared__ double smem[];
     constexpr int CT = COLS / 16, NTH = 64 * NW, HW = NW / 2;
     constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
@@ -135,17 +138,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     double *catt = lmu + NS;               // [COLS][NS] 1 - exp(-dtau/mu): row r = layer l0 - 1 + r
     double *cvec = catt + COLS * NS;       // [7][VL] level vectors of the chunk
     double *cidt = cvec, *cxdel = cvec + VL, *cydel = cvec + 2 * VL, *ccxd = cvec + 3 * VL;
-    double *sbase = bn.scratch + (size_t)blockIdx.x * bn.scr_stride;
-    double *fld = sbase;                                  // [LPB][FS]
-    double *att = fld + (size_t)LPB * FS;                 // [LPB+1][NS]: row i+1 = layer i (levels i..i+1), row 0 zero
-    double *vec = att + (size_t)(LPB + 1) * NS;           // [7][VS]: idtau (layer) | xdel | ydel | cxd | cyd | fxd | fyd
-    double *xin = vec + (size_t)7 * VS;                   // [NCH][KHM]
-    double *acf = xin + (size_t)NCH * KHM;                // [NCH][KHM]
-    double *bcf = acf + (size_t)NCH * KHM;                // [NCH][NS]
-    double *pmid = bcf + (size_t)NCH * NS;                // [NCH][NS] attenuation from the bottom level of a chunk to its middle
-    double *state = pmid + (size_t)NCH * NS;              // [8 + 2 NTH]: status | has_aer | nord | ... | i4, i5 per thread
 
-    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    // One TASK = the Fourier orders [s_begin, s_end) of bin b.  Returns true when the Fourier series of the bin has ended
+    // (stop test, IBORM reached, malformed bin).  Plain launches run one task per workgroup (b = blockIdx.x); the persistent
+    // form (PERSIST) takes tasks from per-XCD queues, see below.
+    // (The per-thread constants are formed inside, from an opaque copy of the thread index: hoisted out of the persistent
+    // form's task loop they would stay live across the whole solve -- 60 more spilled registers.)
+    // PERSIST: the two kernel arguments are re-bound per task through an opaque copy of the kernarg pointer -- as plain
+    // by-value arguments every field the task reads would be loaded once in front of the task loop and kept (or spilled) for
+    // the whole solve.
+    auto bind_cx = [&]() -> decltype(auto) {
+        if constexpr (PERSIST) {
+            const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            return (*(const SosDevK *)ka);
+        } else return (cx_kernel);
+    };
+    auto bind_bn = [&]() -> decltype(auto) {
+        if constexpr (PERSIST) {
+            const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            return (*(const SosBinsK *)(ka + SOS_KERNARG_BINS_OFFSET));
+        } else return (bn_kernel);
+    };
+    auto run_task = [&](const int b, const int s_begin, const int s_end) -> bool {
+    decltype(auto) cx = bind_cx();
+    decltype(auto) bn = bind_bn();
+    int t = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(t));
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool up = wv < HW;               // wave-uniform
     const int kk0 = up ? t : t - 64 * HW;
     const bool active = kk0 < 3 * N;
@@ -165,7 +186,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     const double *bx = cbuf + (lane & 15) * FS + 2 * (lane >> 4);
     double *pcb = cbuf + (lane & 15) * FS + (cx.prow >= 0 ? cx.prow : 0) + (lane >> 4);
 
-    const int b = blockIdx.x;
+    double *sbase = bn.scratch + (size_t)b * bn.scr_stride;
+    double *fld = sbase;                                  // [LPB][FS]
+    double *att = fld + (size_t)LPB * FS;                 // [LPB+1][NS]: row i+1 = layer i (levels i..i+1), row 0 zero
+    double *vec = att + (size_t)(LPB + 1) * NS;           // [7][VS]: idtau (layer) | xdel | ydel | cxd | cyd | fxd | fyd
+    double *xin = vec + (size_t)7 * VS;                   // [NCH][KHM]
+    double *acf = xin + (size_t)NCH * KHM;                // [NCH][KHM]
+    double *bcf = acf + (size_t)NCH * KHM;                // [NCH][NS]
+    double *pmid = bcf + (size_t)NCH * NS;                // [NCH][NS] attenuation from the bottom level of a chunk to its middle
+    double *state = pmid + (size_t)NCH * NS;              // [8 + 2 NTH]: status | has_aer | nord | ... | i4, i5 per thread
     const int nt = uniform_i32(bn.nt[b]);
     const int iborm = uniform_i32(bn.iborm[b]);
     const int jout = ZO ? uniform_i32(bn.jout ? bn.jout[b] : 0) : 0;
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     if (nt < 1 || nt >= LPB || nt >= bn.lp || iborm < 0 || iborm > cx.smax || jout < 0 || jout > nt) {
         if (t == 0) { bn.norders[b] = -1; bn.flux[2 * b] = 0.; bn.flux[2 * b + 1] = 0.; }
         for (int i = t; i < cx.smax + 1; i += NTH) bn.iglast[(size_t)b * (cx.smax + 1) + i] = 0;
-        return;
+        return true;
     }
     const int nchunk = (nt + COLS) / COLS;
     const double *pf = bn.prof + (size_t)b * 3 * bn.lp;
@@ -183,8 +212,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     // an XCD stream the SAME source operator (240 KB at N = 41) from L2 instead of ~20 different ones from the fabric.  The
     // scratch keeps the bin constants (level vectors, attenuations, link factors) and the little state a bin carries from
     // order to order (running Fourier sums I4, I5 of every row, SOS_OS.F:1460-1473) between launches.
-    const bool first = bn.s_begin == 0;
-    if (!first && uniform_f64(state[0]) != 0.) return;          // the Fourier series of this bin has already stopped
+    const bool first = s_begin == 0;
+    // (state written by another workgroup -- an earlier launch, or an earlier task of a persistent launch -- is read with
+    //  agent-scope loads, never through the scalar cache)
+    if (!first && uniform_f64(__hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0.)
+        return true;                                           // the Fourier series of this bin has already stopped
     const double htot = uniform_f64(pf[nt]), h0 = uniform_f64(pf[0]);
     const double hlo = uniform_f64(pf[jlo]), hhi = uniform_f64(pf[jhi]);
     int has_aer;
@@ -248,7 +280,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     if (!SURF && t < N) { lga[t] = cx.ga[t]; lmu[t] = cx.mu[t]; }
     if (SURF) for (int i = t; i < 3 * NS + 2; i += NTH) gnd[i] = 0.;
     for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
-    has_aer = uniform_i32((int)state[1]);
+    has_aer = uniform_i32((int)__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     __syncthreads();
   }
     const double e_sun = uniform_f64(exp(-htot / cx.mus));
@@ -272,16 +304,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     bool finished = false;
     if (!first) {
         i4 = state[8 + 2 * t]; i5 = state[8 + 2 * t + 1];
-        nord = bn.s_begin;
-        if (bn.s_begin & 1) sign = 1.;                   // sign = (-1)^s after the flip at the top of the loop
+        nord = s_begin;
+        if (s_begin & 1) sign = 1.;                   // sign = (-1)^s after the flip at the top of the loop
     }
 #ifdef SOS_PROFILE_PHASES
     unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 stage wait, 1 fix-up, 2 gemm, 3 write-back, 4 sweeps, 5 store, 6 pass end + tests, 7 order-1 passes
 #endif
     PH_T0();
-    const int s_last = min(iborm, bn.s_end - 1);
-    if (bn.s_begin > iborm) finished = true;
-    for (int s = bn.s_begin; s <= s_last; ++s) {  // SOS_OS.F:872
+    const int s_last = min(iborm, s_end - 1);
+    if (s_begin > iborm) finished = true;
+    for (int s = s_begin; s <= s_last; ++s) {  // SOS_OS.F:872
         sign = -sign;
         // ground reflection of the down-going field of the previous order (SOS_OS.F:1166-1239); called by every thread
         const double *gop = SURF ? cx.mp_gnd + (size_t)s * cx.rtph * cx.ks2h * 128 : nullptr;
@@ -653,8 +685,84 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         if (t == 0) bn.norders[b] = nord;
     }
 #ifdef SOS_PROFILE_PHASES
-    if (bn.phase && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&bn.phase[(size_t)b * 8 + k], ph_acc[k]);
+    // SOS_PHASE_ROLE = 1 / 2: stamps of the up-going / down-going waves only (diagnostic: skew between the two halves)
+#ifndef SOS_PHASE_ROLE
+#define SOS_PHASE_ROLE 0
 #endif
+    if (bn.phase && lane == 0 && (SOS_PHASE_ROLE == 0 || (SOS_PHASE_ROLE == 1) == up))
+        for (int k = 0; k < 8; k++) atomicAdd(&bn.phase[(size_t)b * 8 + k], ph_acc[k]);
+#endif
+    return finished;
+    };   // run_task
+
+    if (!PERSIST) {
+        run_task(blockIdx.x, bn.s_begin, bn.s_end);
+        return;
+    }
+    // ---- persistent form: order-scheduled tasks ---------------------------------------------------------------------------
+    // Every workgroup streams the 240 KB source operator of its Fourier order once per chunk; with one workgroup per bin the
+    // 64 workgroups of an XCD sit at ~20 different orders and a fifth of those reads miss the 4 MB L2 (a quarter of the
+    // kernel's fabric traffic).  Here the bins are dealt to the XCDs (bin b -> queue b mod 8) and the workgroups of an XCD --
+    // which one it is read from HW_REG_XCC_ID -- take tasks (order s, bin) from their XCD's queue in the order s-major: at any
+    // time they work on one or two orders and share their operators in L2.  The queue is one atomic counter; task c of a queue
+    // with nq bins is (s = c / nq, bin = c mod nq).  A task starts when its bin has completed order s - 1: flag[bin] counts the
+    // completed orders (FIN: the series has ended), published with an agent-scope release by the workgroup that ran them and
+    // acquired by the taker -- a workgroup only ever waits for a task taken earlier from the same queue by a workgroup that
+    // is running, so the waits cannot cycle.  A workgroup whose queue is exhausted takes tasks from the other queues (also what
+    // makes the result independent of where the hardware places workgroups).
+    constexpr int FIN = 0x7fffffff;
+    const int t = threadIdx.x, S1 = cx.smax + 1;
+    int *ired = reinterpret_cast<int *>(red) + 24;             // task broadcast (block_or_* use the first 2 NW ints of red)
+    const int my_xcd = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7;   // hwreg(HW_REG_XCC_ID, 0, 4)
+    const int nbins = bn.nb;
+    for (int hop = 0; hop < 8; hop++) {
+        const int q = (my_xcd + hop) & 7;
+        const int nq = (nbins - q + 7) >> 3;                   // bins q, q + 8, ... of this queue
+        if (nq <= 0) continue;
+        for (;;) {
+            __syncthreads();                                   // the previous task's last LDS reads / ired reads are done
+            if (t == 0) {
+                int tb = -1, ts = 0;
+                for (;;) {
+                    // all bins of the queue finished -> nothing left here (bins in flight are finished by their holders)
+                    if (__hip_atomic_load(&bn.queue[16 * (8 + q)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq) break;
+                    const int c = __hip_atomic_fetch_add(&bn.queue[16 * q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ts = c / nq;
+                    if (ts >= S1) break;
+                    const int cand = q + 8 * (c - ts * nq);
+                    int f;
+                    while ((f = __hip_atomic_load(&bn.qflag[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ts)
+                        __builtin_amdgcn_s_sleep(8);
+                    if (f != FIN) { tb = cand; break; }
+                }
+                int te = ts + 1;
+                if (tb >= 0 && nq - __hip_atomic_load(&bn.queue[16 * (8 + q)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= bn.q_tail) {
+                    // the tail of the queue: fewer unfinished bins than workgroups to run them order by order -- this
+                    // workgroup keeps the bin for all its remaining orders; nobody else will touch it (flag = FIN at once)
+                    te = S1;
+                    __hip_atomic_store(&bn.qflag[tb], FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&bn.queue[16 * (8 + q)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ired[0] = tb; ired[1] = ts; ired[2] = te;
+            }
+            __syncthreads();
+            const int tb = uniform_i32(ired[0]), ts = uniform_i32(ired[1]), te = uniform_i32(ired[2]);
+            if (tb < 0) break;
+            const bool fin = run_task(tb, ts, te);
+            if (te == S1) continue;                            // kept to the end: nothing to hand over
+            // publish: every wave's stores have left the CU, then one lane releases and raises the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&bn.qflag[tb], fin ? FIN : ts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fin) __hip_atomic_fetch_add(&bn.queue[16 * (8 + q)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -683,19 +791,39 @@ size_t sos_stream_scratch_doubles(int n, int lpb)
 template <int NW, int RTWH, bool ZO, bool SURF>
 static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_t st, int *hip_err)
 {
-    auto kern = k_sos_stream<NW, RTWH, ZO, SURF>;
+#ifdef SOS_MULTI
+    const bool persist = false;                            // (the per-bin context is bound to blockIdx.x)
+    if (bn.queue) return SOSGPU_E_UNSUPPORTED;
+    auto kern = k_sos_stream<NW, RTWH, ZO, SURF, false>;
+#else
+    const bool persist = bn.queue != nullptr;
+    auto kern = persist ? k_sos_stream<NW, RTWH, ZO, SURF, true> : k_sos_stream<NW, RTWH, ZO, SURF, false>;
+#endif
     const size_t lds = stream_lds_bytes(NW, RTWH);
     // the dynamic-LDS limit of a kernel is set once per device and size (the call costs tens of microseconds: with few bins per
     // wavelength the host launch path is what bounds a hyperspectral loop, scripts/spectrum_bench.py)
-    static size_t configured[16] = {0};
+    static size_t configured[2][16] = {{0}, {0}};
+    static int cus[16] = {0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[dev] < lds)) {
+    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[persist][dev] < lds)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess && dev >= 0 && dev < 16) configured[dev] = lds;
+        if (e == hipSuccess && dev >= 0 && dev < 16) configured[persist][dev] = lds;
     }
+    int grid = bn.nb;
+    if (e == hipSuccess && persist) {
+        // as many workgroups as the chip hosts at once (two per CU for the 4-wave forms); fewer resident ones only cost speed
+        int ncu = (dev >= 0 && dev < 16) ? cus[dev] : 0;
+        if (!ncu) {
+            e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e == hipSuccess && dev >= 0 && dev < 16) cus[dev] = ncu;
+        }
+        grid = std::min(bn.nb, ncu * (NW == 4 ? 2 : 1));
+    }
+    SosBins bq = bn;
+    if (persist && bq.q_tail < 0) bq.q_tail = 2 * ((grid + 7) / 8);     // unfinished bins per queue below which bins are kept
     if (e == hipSuccess) {
-        kern<<<bn.nb, 64 * NW, lds, st>>>(cx, bn);
+        kern<<<grid, 64 * NW, lds, st>>>(cx, bq);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return -2; }

@@ -991,6 +991,44 @@ def sos_proc(aer_phase=None, device=0, **kw):
             tdir_vrai, flux_diff_down, flux_down, eplus, a_tronc if coef_tronca_out is None else coef_tronca_out)
 
 
+def sos_proc_many(kwargs_list, n_workers=8, device=0):
+    """A spectrum of independent sos_proc calls (one per wavelength: the reference runs them one after the other,
+    binding/run_sos.py:640) issued from `n_workers` host threads, each on its own HIP stream.  One call spends most of its
+    wall clock waiting for the few bins of its band (a bin is a serial chain of scattering orders: milliseconds on a small
+    fraction of the chip); here the waits of one wavelength overlap the host work and the kernels of the others.  Every call
+    is the unchanged sos_proc -- results are identical to the sequential loop.  Give each call its own `-SOS_Main.ResRoot`
+    when result files are wanted (the file names inside are fixed, as in the reference).  Export GPU_MAX_HW_QUEUES=16 before
+    the first GPU call (solver.solve_many).  Returns the list of 23-tuples in order; the first failing call's exception is
+    raised after all calls have ended."""
+    import concurrent.futures
+    import torch
+    from . import capi
+    capi.lib()                                             # loaded once, before the threads
+    if not kwargs_list:
+        return []
+    dev = torch.device("cuda", device)
+    nw = max(1, min(int(n_workers), len(kwargs_list)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]
+    import threading
+    slot = threading.local()
+    free = list(range(nw))
+    lock = threading.Lock()
+
+    def one(kw):
+        if not hasattr(slot, "i"):
+            with lock:
+                slot.i = free.pop()
+        with torch.cuda.device(dev), torch.cuda.stream(streams[slot.i]):
+            out = sos_proc(device=device, **kw)
+            streams[slot.i].synchronize()
+        return out
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=nw) as ex:
+        futs = [ex.submit(one, kw) for kw in kwargs_list]
+        concurrent.futures.wait(futs)
+    return [f.result() for f in futs]
+
+
 def write_trans_file(path, tetas, mu, ttot_tronc, ttot_vrai, tdifmus, tdifmug):
     """-SOS.Trans file (SOS_PROC.F:3785-3822, formats 1005, 1006, 1010, 2010): direct transmission for the true optical
     depth, diffuse transmissions brought back to the true atmosphere by + exp(-tau_tr/mu) - exp(-tau/mu)."""

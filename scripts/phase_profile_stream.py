@@ -17,7 +17,7 @@ ph = torch.zeros((nb, 8), dtype=torch.int64, device=cx.device)
 pkg.capi.check(pkg.capi.lib().sosgpu_debug_phase_buffer(cx._h, C.c_void_p(ph.data_ptr())), "phase")
 out = cx.solve(bins)
 torch.cuda.synchronize()
-p = ph.cpu().numpy().astype(np.float64) / 4.0     # 4 waves add their own stamps
+p = ph.cpu().numpy().astype(np.float64) / float(os.environ.get("PHASE_WAVES", "4"))     # the waves add their own stamps (2 for the SOS_PHASE_ROLE builds)
 nt = bins["nt"].cpu().numpy()
 igl = out["iglast"].cpu().numpy()
 nch = (nt + 32) // 32

@@ -320,3 +320,58 @@ def test_context_table_rejects_mismatched_contexts(gpu_pkg):
     gpu_pkg.solver.ContextTable((a, a))
     for cx in (a, b, c):
         cx.close()
+
+
+STREAM_CASES = ["rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600"]
+
+
+@pytest.mark.parametrize("mode", ["persistent_order_scheduled", "one_order_per_launch", "three_orders_per_launch"])
+@pytest.mark.parametrize("name", STREAM_CASES)
+def test_streamed_solver_launch_forms_vs_golden(gpu_pkg, monkeypatch, name, mode):
+    """The streamed solver's default is one workgroup per bin (covered by the tests above); its other launch forms -- ONE
+    persistent launch with order-scheduled tasks from per-XCD queues, and order-synchronous launches -- give the same records
+    against the reference."""
+    import os
+    if mode == "persistent_order_scheduled":
+        monkeypatch.setenv("SOSGPU_STREAM_PERSIST", "1")
+    else:
+        monkeypatch.setenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH", "1" if mode == "one_order_per_launch" else "3")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sos_os_%s.npz" % name))
+    case = cases.make_case(name)
+    got = cases.run_gpu(gpu_pkg, case)
+    for b, r in enumerate(got):
+        assert np.array_equal(r["ig_counts"], g["ig%d" % b]), (name, b)
+        cases.compare_records(r["records"], g["rec%d" % b], 1e-9, "%s bin %d" % (name, b))
+        assert np.allclose([r["emoins"], r["eplus"]], g["flux%d" % b], rtol=1e-9, atol=0)
+
+
+def test_streamed_persistent_many_bins_bitwise_equal_to_per_bin_launch(gpu_pkg, monkeypatch):
+    """More bins than the chip hosts workgroups, ragged level counts, a malformed bin in the middle: the persistent
+    order-scheduled launch returns bit for bit what the one-workgroup-per-bin launch returns."""
+    import torch
+    S = gpu_pkg.synth
+    mu, w, n0 = S.gauss_angles(12, 35.0)
+    al, be, ga, ze = S.hg_phase(24, 0.7)
+    nb = 1500
+    rng = np.random.default_rng(3)
+    b = S.ckd_bins(nb, 140, seed=9)
+    h, x, y, iborm = S.rescale_profile(b["h"], b["xdel"], b["ydel"], 0.0, 0.95, 0.95, 24)
+    nt = rng.integers(66, 141, nb).astype(np.int32)
+    nt[700] = 0                                            # malformed: flagged norders = -1, the others unaffected
+    cx = gpu_pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=24, ro=0.2)
+    bins = cx.upload_bins(h, x, y, nt=nt, iborm=rng.integers(0, 25, nb).astype(np.int32))
+    monkeypatch.setenv("SOSGPU_STREAM_PERSIST", "1")
+    monkeypatch.setenv("SOSGPU_STREAM_QTAIL", "16")        # order-by-order hand-overs until 16 bins per queue are left
+    out_p = cx.solve(bins)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("SOSGPU_STREAM_PERSIST", "0")
+    out_b = cx.solve(bins)
+    torch.cuda.synchronize()
+    assert int(out_p["norders"][700]) == -1 and int((out_p["norders"] > 0).sum()) == nb - 1
+    for k in ("norders", "iglast", "flux"):
+        assert torch.equal(out_p[k], out_b[k]), k
+    no = out_p["norders"].cpu().numpy()
+    rp, rb = out_p["rec"].cpu().numpy(), out_b["rec"].cpu().numpy()
+    for i in range(nb):
+        assert np.array_equal(rp[i, :max(no[i], 0)], rb[i, :max(no[i], 0)]), i
+    cx.close()

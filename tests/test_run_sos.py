@@ -194,3 +194,42 @@ def test_sos_proc_random_keyword_sets_vs_reference(gpu_pkg, name, tmp_path, monk
         coef = 0.0
     out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
     cases.compare_proc_outputs(rs, out, g, coef_tronca=coef, rtol=2e-7 if int(user["-SURF.Type"]) >= 3 else 1e-9)
+
+
+@pytest.mark.gpu
+def test_sos_proc_many_threads_and_streams_vs_reference(gpu_pkg, tmp_path, monkeypatch):
+    """run_sos.sos_proc_many: the 20 random keyword sets (each repeated twice: 40 calls) issued from 6 host threads on their own
+    HIP streams, every one writing its result files into its own directory -- each call's 23 outputs still match the compiled
+    reference's, and the two copies of a call are bit-identical (no cross-talk between concurrent wavelengths)."""
+    rs = gpu_pkg.run_sos
+    monkeypatch.setenv("SOS_ABS_ROOT", GOLD)
+    kws, golds, coefs = [], [], []
+    for rep in range(2):
+        for name in RANDOM_CASES:
+            g = np.load(os.path.join(GOLD, "sos_proc_%s.npz" % name))
+            user = {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v)
+                    for k, v in json.loads(str(g["user_json"])).items()}
+            d = tmp_path / ("%s_%d" % (name, rep))
+            d.mkdir()
+            user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT", "-SOS_Main.ResRoot": str(d)})
+            coef = None
+            if user["-AER.AOTref"] != 0.0:
+                f = str(d / "Aerosols_user.txt")
+                rs.write_aerosols_file(f, {k: g["aer_" + k] for k in ("alpha", "beta", "gamma", "zeta", "a_tronc", "piztr", "piz")},
+                                       *g["kmat"])
+                user["-AER.UserFile"] = f
+                coef = 0.0
+            kws.append(rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
+            golds.append((g, int(user["-SURF.Type"])))
+            coefs.append(coef)
+    outs = rs.sos_proc_many(kws, n_workers=6)
+    assert len(outs) == len(kws)
+    for out, (g, isurf), coef in zip(outs, golds, coefs):
+        cases.compare_proc_outputs(rs, out, g, coef_tronca=coef, rtol=2e-7 if isurf >= 3 else 1e-9)
+    n = len(RANDOM_CASES)
+    for i in range(n):
+        for a, b in zip(outs[i], outs[i + n]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), RANDOM_CASES[i]
+    with pytest.raises(rs.SosProcError):                   # a failing call surfaces after the others have ended
+        bad = dict(kws[0]); bad["isurf"] = 6
+        rs.sos_proc_many([kws[1], bad, kws[2]], n_workers=2)
