@@ -228,7 +228,7 @@ def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g):
                            mean_fourier_orders=float(nord.mean()), mean_scattering_steps=float(nsteps.mean())),
                roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                              traffic=pmc_traffic("_realistic", bins_per_gpu=nbins),
-                             kernel="k_sos_stream<4,2,false,false>", kernel_ms=kms, bytes_per_launch=bytes_alg,
+                             kernel="k_sos_stream<4,2,false,false,false>", kernel_ms=kms, bytes_per_launch=bytes_alg,
                              bytes_counted="field written once per scattering order and read once per order >= 2: "
                                            "(NT+1) x 6N x 8 B each",
                              mfma_tflops=tf, mfma_frac=tf / FP64_PEAK_TFLOPS))
