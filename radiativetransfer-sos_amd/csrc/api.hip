@@ -319,7 +319,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
     const int nt_max = lp - 1;          // lp - 1 bounds every NT of the batch (the host pads the level axis to lp)
     int rc = sos_os_variant(cx->d.n, nt_max, &nw, &rtw, &ct, &lds, &big);
     if (rc) return rc;
-    int per_launch = nb;
+    int per_launch = nb, spec_k = 0;
     const int lpb = sos_round_up(lp, 32);
     const size_t per_bin = big ? sos_stream_scratch_doubles(cx->d.n, lpb) : 0;
     if (big) {
@@ -328,8 +328,24 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (const char *e = getenv("SOSGPU_SCRATCH_GIB")) { const long v = atol(e); if (v > 0) gib = (size_t)v; }
         const size_t cap = (gib << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
+        // Few bins (a band of one wavelength): the order-parallel form -- K Fourier orders of every bin at a time, each in a
+        // work region of its own, so that the band fills ~1024 workgroup slots (sos_stream.hip; SOSGPU_STREAM_SPEC=0 turns it
+        // off, SOSGPU_STREAM_SPEC_MAXBINS moves the limit).  A single bin takes 11 ms as one workgroup, ~1.5 ms this way.
+        int spec_max = 128;
+        if (const char *e = getenv("SOSGPU_STREAM_SPEC")) { if (atoi(e) == 0) spec_max = 0; }
+        if (const char *e = getenv("SOSGPU_STREAM_SPEC_MAXBINS")) spec_max = atoi(e);
+        if (const char *e = getenv("SOSGPU_STREAM_PERSIST")) { if (atoi(e) != 0) spec_max = 0; }      // explicitly chosen forms win
+        if (const char *e = getenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH")) { if (atoi(e) > 0) spec_max = 0; }
+        const int s1n = cx->d.smax + 1;
+        if (!table && nb <= spec_max && s1n > 1) {
+            spec_k = std::min(s1n, std::max(2, 1024 / nb));
+            if (const char *e = getenv("SOSGPU_STREAM_SPEC_K")) spec_k = std::min(s1n, std::max(1, atoi(e)));   // (tests)
+            if ((size_t)nb * spec_k * per_bin > cap) spec_k = 0;
+        }
+        const size_t regions = spec_k ? (size_t)nb * spec_k : (size_t)per_launch;
+        const size_t i3_doubles = spec_k ? (size_t)nb * s1n * sos_stream_threads(cx->d.n) : 0;
         // + the task queues and per-bin order flags of the persistent form (ints, behind the bins' scratch)
-        const size_t need = per_bin * per_launch + (256 + (size_t)per_launch) / 2 + 1;
+        const size_t need = per_bin * regions + i3_doubles + (256 + (size_t)per_launch) / 2 + 1;
         if (need > cx->scratch_doubles) {
             HIPCHK(hipDeviceSynchronize());     // a solve of this context may still be in flight on another stream
             if (cx->scratch) (void)hipFree(cx->scratch);
@@ -352,9 +368,21 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
         bn.ctxs = table; bn.ctx_of_bin = table ? d_ctx_of_bin + b0 : nullptr;
         bn.queue = bn.qflag = nullptr; bn.q_tail = -1;
+        bn.spec_k = 0; bn.spec_i3 = nullptr;
         if (const char *e = getenv("SOSGPU_STREAM_QTAIL")) bn.q_tail = atoi(e);
         bn.s_begin = 0; bn.s_end = S1;
-        if (big) {
+        if (big && spec_k) {
+            // order-parallel form: set-up launch, then rounds of (K order tasks per bin, replay of their stop tests)
+            bn.spec_i3 = cx->scratch + per_bin * (size_t)nb * spec_k;
+            bn.spec_k = -spec_k; bn.s_begin = 0; bn.s_end = 0;
+            rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
+            bn.spec_k = spec_k;
+            for (int s0 = 0; s0 < S1 && rc == 0; s0 += spec_k) {
+                bn.s_begin = s0; bn.s_end = std::min(S1, s0 + spec_k);
+                rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
+                if (rc == 0) rc = launch_sos_stream_replay(cx->d, bn, bn.s_begin, bn.s_end, st, &g_last_hip);
+            }
+        } else if (big) {
             // The streamed kernel can run `opl` Fourier orders of every bin per launch (order-synchronous launches: every
             // workgroup then streams the same source operator).  Measured on the realistic mix (profiles/r02_stream_experiments.txt):
             // 1 order per launch 21.1k bins/s, all orders in one launch 21.9k -- the operator stream is not what binds, so one

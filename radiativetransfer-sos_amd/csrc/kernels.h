@@ -14,6 +14,9 @@ int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_by
 // bn.scratch holds bn.scr_stride >= sos_stream_scratch_doubles(n, lpb) doubles per bin, lpb a multiple of 32.
 int launch_sos_stream(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err);
 size_t sos_stream_scratch_doubles(int n, int lpb);
+// order-parallel form (bn.spec_k): the Fourier stop tests of orders [s0, s1) of every bin, after the order tasks of a round
+int launch_sos_stream_replay(const SosDev &cx, const SosBins &bn, int s0, int s1, hipStream_t st, int *hip_err);
+int sos_stream_threads(int n);
 // the same two solvers with a per-bin context (bn.ctxs, bn.ctx_of_bin; sos_os_multi.hip, sos_stream_multi.hip): `cx` is any
 // context of the table -- it selects the variant (N, surface-matrix flag), which the caller guarantees equal over the table
 int launch_sos_os_multi(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err);

@@ -75,6 +75,10 @@ struct SosBins {
     int *queue, *qflag;
     int q_tail;                  // a queue with at most this many unfinished bins hands out whole bins (all remaining orders);
                                  // < 0: the launcher's default (twice the workgroups per queue)
+    // order-parallel form of the streamed variant for few bins (sos_stream.hip): spec_k = -K set-up launch, K > 0 order tasks
+    // (grid nb K: workgroup (b, j) runs order s_begin + j), 0 otherwise; spec_i3[nb][smax+1][threads] I3 terms of every order
+    int spec_k;
+    double *spec_i3;
     // multi-wavelength launches (sos_os_multi.hip / sos_stream_multi.hip): bin b runs with the context ctxs[ctx_of_bin[b]]
     // of a device-resident context table instead of the kernel argument; null otherwise
     const SosDev *ctxs;

@@ -161,7 +161,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
             return (*(const SosBinsK *)(ka + SOS_KERNARG_BINS_OFFSET));
         } else return (bn_kernel);
     };
-    auto run_task = [&](const int b, const int s_begin, const int s_end) -> bool {
+    // rc / rw: scratch regions holding the bin's constants (attenuations, level vectors, link factors, state) and this task's
+    // work arrays (field, chunk inflows); the same region except in the order-parallel form (SPEC, below), where `spec` is set:
+    // the task then runs ONE order without the bin's Fourier sums -- it leaves its I3 terms in bn.spec_i3 and the stop test
+    // to k_sos_stream_replay.
+    auto run_task = [&](const int b, const int s_begin, const int s_end, const size_t rc, const size_t rw, const bool spec) -> bool {
     decltype(auto) cx = bind_cx();
     decltype(auto) bn = bind_bn();
     int t = threadIdx.x;
@@ -186,13 +190,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     const double *bx = cbuf + (lane & 15) * FS + 2 * (lane >> 4);
     double *pcb = cbuf + (lane & 15) * FS + (cx.prow >= 0 ? cx.prow : 0) + (lane >> 4);
 
-    double *sbase = bn.scratch + (size_t)b * bn.scr_stride;
-    double *fld = sbase;                                  // [LPB][FS]
-    double *att = fld + (size_t)LPB * FS;                 // [LPB+1][NS]: row i+1 = layer i (levels i..i+1), row 0 zero
+    double *cbase = bn.scratch + rc * bn.scr_stride, *wbase = bn.scratch + rw * bn.scr_stride;
+    double *fld = wbase;                                  // [LPB][FS]
+    double *att = cbase + (size_t)LPB * FS;               // [LPB+1][NS]: row i+1 = layer i (levels i..i+1), row 0 zero
     double *vec = att + (size_t)(LPB + 1) * NS;           // [7][VS]: idtau (layer) | xdel | ydel | cxd | cyd | fxd | fyd
-    double *xin = vec + (size_t)7 * VS;                   // [NCH][KHM]
+    const size_t off_xin = (size_t)LPB * FS + (size_t)(LPB + 1) * NS + (size_t)7 * VS;
+    double *xin = wbase + off_xin;                        // [NCH][KHM]
     double *acf = xin + (size_t)NCH * KHM;                // [NCH][KHM]
-    double *bcf = acf + (size_t)NCH * KHM;                // [NCH][NS]
+    double *bcf = cbase + off_xin + (size_t)2 * NCH * KHM;   // [NCH][NS]
     double *pmid = bcf + (size_t)NCH * NS;                // [NCH][NS] attenuation from the bottom level of a chunk to its middle
     double *state = pmid + (size_t)NCH * NS;              // [8 + 2 NTH]: status | has_aer | nord | ... | i4, i5 per thread
     const int nt = uniform_i32(bn.nt[b]);
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     // an XCD stream the SAME source operator (240 KB at N = 41) from L2 instead of ~20 different ones from the fabric.  The
     // scratch keeps the bin constants (level vectors, attenuations, link factors) and the little state a bin carries from
     // order to order (running Fourier sums I4, I5 of every row, SOS_OS.F:1460-1473) between launches.
-    const bool first = s_begin == 0;
+    const bool first = s_begin == 0 && !spec;
+    if (spec && s_begin > iborm) return false;                 // an order the bin never runs
     // (state written by another workgroup -- an earlier launch, or an earlier task of a persistent launch -- is read with
     //  agent-scope loads, never through the scalar cache)
     if (!first && uniform_f64(__hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0.)
@@ -281,6 +287,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     if (SURF) for (int i = t; i < 3 * NS + 2; i += NTH) gnd[i] = 0.;
     for (int i = t; i < COLS * FS; i += NTH) cbuf[i] = 0.;
     has_aer = uniform_i32((int)__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // a work region of its own: the levels above nt of the last chunk are loaded, never stored -- zero them here
+    if (spec) for (size_t i = (size_t)(nt + 1) * FS + t; i < (size_t)nchunk * COLS * FS; i += NTH) fld[i] = 0.;
     __syncthreads();
   }
     const double e_sun = uniform_f64(exp(-htot / cx.mus));
@@ -671,12 +679,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         }
         if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
         nord = s + 1;
+        if (spec) bn.spec_i3[((size_t)b * S1 + s) * NTH + t] = i3;     // (the test below runs on partial sums: its result is not used)
         PH(6);
         const double a3 = fabs(i3);                                                                 // SOS_ARRET_FOURIER
         const bool pf = active && ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5)));
         const int pf2 = block_or_bits<NW>(pf, reinterpret_cast<int *>(red), wv, lane, red_slot);
         if (!pf2 || s == iborm) { finished = true; break; }                          // SOS_OS.F:1585
     }
+    if (spec) return false;
     if (finished) {
         for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
         if (t == 0) { bn.norders[b] = nord; state[0] = 1.; }
@@ -696,7 +706,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     };   // run_task
 
     if (!PERSIST) {
-        run_task(blockIdx.x, bn.s_begin, bn.s_end);
+        // Order-parallel form for FEW bins (a band of 1-100 bins leaves most of the chip idle while every bin walks through
+        // its Fourier orders one after the other -- 11 ms for a single bin): the orders of a bin do not depend on each
+        // other, only the Fourier stop test does (running sums I4, I5 over the orders, SOS_OS.F:1460-1473,1585).  bn.spec_k =
+        // -K: set-up launch, one workgroup per bin writes the bin's constants into region b K.  bn.spec_k = K > 0: workgroup
+        // (b, j) runs order s_begin + j of bin b in its own work region b K + j and stores its I3 terms; k_sos_stream_replay
+        // then replays the stop tests of these K orders in sequence.  Orders past the stop are wasted work on idle CUs.
+        const int K = bn.spec_k;
+        if (K < 0) run_task(blockIdx.x, 0, 0, (size_t)blockIdx.x * (size_t)(-K), (size_t)blockIdx.x * (size_t)(-K), false);
+        else if (K > 0) {
+            const int b = blockIdx.x / K, j = blockIdx.x - b * K;
+            if (bn.s_begin + j < bn.s_end) run_task(b, bn.s_begin + j, bn.s_begin + j + 1, (size_t)b * K, (size_t)b * K + j, true);
+        } else run_task(blockIdx.x, bn.s_begin, bn.s_end, blockIdx.x, blockIdx.x, false);
         return;
     }
     // ---- persistent form: order-scheduled tasks ---------------------------------------------------------------------------
@@ -750,7 +771,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
             __syncthreads();
             const int tb = uniform_i32(ired[0]), ts = uniform_i32(ired[1]), te = uniform_i32(ired[2]);
             if (tb < 0) break;
-            const bool fin = run_task(tb, ts, te);
+            const bool fin = run_task(tb, ts, te, tb, tb, false);
             if (te == S1) continue;                            // kept to the end: nothing to hand over
             // publish: every wave's stores have left the CU, then one lane releases and raises the flag
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -762,6 +783,47 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
                 if (fin) __hip_atomic_fetch_add(&bn.queue[16 * (8 + q)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
+}
+
+// Order-parallel form, second half: the Fourier stop test (SOS_ARRET_FOURIER, SOS_OS.F:3709; accumulation :1460-1473, exit
+// :1585) of orders [s0, s1) of every bin, replayed in sequence from the I3 terms the order tasks left in bn.spec_i3 -- the same
+// statements as at the end of run_task's order loop, with the same thread -> row mapping.  One workgroup per bin.
+template <int NW, int RTWH>
+__global__ __launch_bounds__(64 * NW) void k_sos_stream_replay(const SosDev cx, const SosBins bn, int s0, int s1)
+{
+    __shared__ int red[2 * NW];
+    constexpr int NTH = 64 * NW, HW = NW / 2, KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
+    const int LPB = bn.lpb, NCH = LPB / COLS, VS = LPB + VPAD, N = cx.n, S1 = cx.smax + 1;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (uniform_i32(bn.norders[b]) < 0) return;                     // malformed bin (flagged by the set-up launch)
+    double *state = bn.scratch + (size_t)b * (size_t)bn.spec_k * bn.scr_stride + (size_t)LPB * FS + (size_t)(LPB + 1) * NS +
+                    (size_t)7 * VS + (size_t)NCH * (2 * KHM + 2 * NS);
+    if (uniform_f64(state[0]) != 0.) return;                        // finished in an earlier round
+    const int iborm = uniform_i32(bn.iborm[b]);
+    const bool up = wv < HW;
+    const bool active = (up ? t : t - 64 * HW) < 3 * N;
+    double i4 = state[8 + 2 * t], i5 = state[8 + 2 * t + 1];
+    int nord = s0, red_slot = 0;
+    bool finished = s0 > iborm;
+    for (int s = s0; s < s1 && !finished; ++s) {
+        const double sign = (s & 1) ? -1. : 1.;
+        const double i3 = bn.spec_i3[((size_t)b * S1 + s) * NTH + t];
+        const double coef = (s == 0) ? 1. : 2.;
+        i4 = i4 + coef * i3;
+        i5 = i5 + coef * i3 * sign;
+        nord = s + 1;
+        const double a3 = fabs(i3);
+        const bool pf = active && ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5)));
+        const int pf2 = block_or_bits<NW>(pf, red, wv, lane, red_slot);
+        if (!pf2 || s == iborm) finished = true;
+    }
+    if (finished) {
+        for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
+        if (t == 0) { bn.norders[b] = nord; state[0] = 1.; }
+    } else {
+        state[8 + 2 * t] = i4; state[8 + 2 * t + 1] = i5;
+        if (t == 0) bn.norders[b] = nord;
     }
 }
 
@@ -810,7 +872,7 @@ static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess && dev >= 0 && dev < 16) configured[persist][dev] = lds;
     }
-    int grid = bn.nb;
+    int grid = bn.spec_k > 0 ? bn.nb * bn.spec_k : bn.nb;
     if (e == hipSuccess && persist) {
         // as many workgroups as the chip hosts at once (two per CU for the 4-wave forms); fewer resident ones only cost speed
         int ncu = (dev >= 0 && dev < 16) ? cus[dev] : 0;
@@ -829,6 +891,27 @@ static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_
     if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return -2; }
     return 0;
 }
+
+#ifndef SOS_MULTI
+int sos_stream_threads(int n)
+{
+    int nw, rtw;
+    stream_shape(n, &nw, &rtw);
+    return 64 * nw;
+}
+
+int launch_sos_stream_replay(const SosDev &cx, const SosBins &bn, int s0, int s1, hipStream_t st, int *hip_err)
+{
+    int nw, rtw;
+    stream_shape(cx.n, &nw, &rtw);
+    if (nw == 4 && rtw == 1) k_sos_stream_replay<4, 1><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
+    else if (nw == 4) k_sos_stream_replay<4, 2><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
+    else k_sos_stream_replay<8, 2><<<bn.nb, 512, 0, st>>>(cx, bn, s0, s1);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return -2; }
+    return 0;
+}
+#endif
 
 int launch_sos_stream(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err)
 {

@@ -24,8 +24,10 @@ Differences from the reference script that are deliberate: errors ra
 lost in an `intent(in)` `ier`; `gen_sos_output` imports `ceil` and uses `and` (the reference has `1 & updown == 2`);
 files are written only when `-SOS_Main.ResRoot` is given (RESROOT/SOS/SOS_Result.bin, the -SOS.Trans / -SOS.Flux files).
 """
+import collections
 import math
 import os
+import threading
 
 import numpy as np
 
@@ -714,6 +716,30 @@ def validate_parameters(p):
         fail(2611, "-SOS.OutputAlt must be -1 (standard levels) or within [0, %g] km" % CTE_TOA_ALT)
 
 
+# Surface reflection matrices of the last few (surface, angles) combinations: they do not depend on the wavelength, so a
+# spectrum of calls over one surface computes them once (SOS_SURFACE has the same idea with its SURFACE/ directory of files,
+# SOS_SURFACE.F:260-330).  The tensors are read-only after the stream that made them has been synchronised.
+_SURF_CACHE = collections.OrderedDict()
+_SURF_LOCK = threading.Lock()
+_SURF_CACHE_MAX = 8
+
+
+def _surface_cached(key, make, device):
+    import torch
+    with _SURF_LOCK:
+        hit = _SURF_CACHE.get(key)
+        if hit is not None:
+            _SURF_CACHE.move_to_end(key)
+            return hit
+    r = make()
+    torch.cuda.current_stream(torch.device("cuda", device)).synchronize()
+    with _SURF_LOCK:
+        _SURF_CACHE[key] = r
+        while len(_SURF_CACHE) > _SURF_CACHE_MAX:
+            _SURF_CACHE.popitem(last=False)
+    return r
+
+
 def sos_proc(aer_phase=None, device=0, **kw):
     """Drop-in for `sos.sos_proc(**kwargs)` (f2py of SOS_PROC, SOS_PROC.F:415) on the MI355X hot path.
     Returns the reference's 23-tuple (names in OUTPUT_NAMES).
@@ -870,10 +896,16 @@ def sos_proc(aer_phase=None, device=0, **kw):
     elif isurf == 1:
         if p["wind"] == _D:
             raise SosProcError("-SURF.Glitter.Wind must be defined")
-        rsurf = _surface.glitter_matrices(mu, ga, p["wind"], p["surf_ind"], os_nb, os_ns, os_nm, device=device)["rsurf"]
+        key = ("glitter", mu.tobytes(), ga.tobytes(), float(p["wind"]), float(p["surf_ind"]), os_nb, os_ns, os_nm, device)
+        rsurf = _surface_cached(key, lambda: _surface.glitter_matrices(mu, ga, p["wind"], p["surf_ind"], os_nb, os_ns, os_nm,
+                                                                        device=device)["rsurf"], device)
     elif land is not None:
+        ind_l = p["surf_ind"] if isurf >= 4 else 1.0
+        key = ("land", isurf, float(land.k0), float(land.k1), float(land.k2), float(land.alpha), float(land.beta),
+               float(land.coef_c), mu.tobytes(), ga.tobytes(), float(ind_l), os_nb, os_ns, os_nm, device)
         try:
-            rsurf = _surface.land_matrices(land, mu, ga, p["surf_ind"] if isurf >= 4 else 1.0, os_nb, os_ns, os_nm, device=device)
+            rsurf = _surface_cached(key, lambda: _surface.land_matrices(land, mu, ga, ind_l, os_nb, os_ns, os_nm, device=device),
+                                    device)
         except ValueError as e:
             raise SosProcError(str(e), ier=-1)
     if rsurf is not None and iborm < os_nb:

@@ -296,8 +296,11 @@ def test_solve_spectrum_one_launch_for_many_wavelengths(gpu_pkg, n, nt, surf, zo
     b0 = 0
     for i, (o, r0, s0) in enumerate(ref):
         nbw = o["rec"].shape[0]
-        for k in ("rec", "norders", "iglast", "flux"):
+        for k in ("norders", "iglast", "flux"):
             assert torch.equal(out[k][b0:b0 + nbw], o[k]), (i, k)
+        for j in range(nbw):                               # (orders past a bin's stop hold nothing the results depend on)
+            f = int(o["norders"][j])
+            assert torch.equal(out["rec"][b0 + j, :f], o["rec"][j, :f]), (i, j)
         assert torch.equal(rec[i], r0[0]) and torch.equal(scal[i], s0[0]), i
         b0 += nbw
     assert int(out["norders"].min()) > 0
@@ -325,14 +328,16 @@ def test_context_table_rejects_mismatched_contexts(gpu_pkg):
 STREAM_CASES = ["rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600"]
 
 
-@pytest.mark.parametrize("mode", ["persistent_order_scheduled", "one_order_per_launch", "three_orders_per_launch"])
+@pytest.mark.parametrize("mode", ["one_workgroup_per_bin", "persistent_order_scheduled", "one_order_per_launch", "three_orders_per_launch"])
 @pytest.mark.parametrize("name", STREAM_CASES)
 def test_streamed_solver_launch_forms_vs_golden(gpu_pkg, monkeypatch, name, mode):
-    """The streamed solver's default is one workgroup per bin (covered by the tests above); its other launch forms -- ONE
-    persistent launch with order-scheduled tasks from per-XCD queues, and order-synchronous launches -- give the same records
-    against the reference."""
+    """The streamed solver runs few bins in its order-parallel form (the tests above: their batches are small) and many bins
+    with one workgroup per bin; that form forced for the small cases, ONE persistent launch with order-scheduled tasks from
+    per-XCD queues, and order-synchronous launches give the same records against the reference."""
     import os
-    if mode == "persistent_order_scheduled":
+    if mode == "one_workgroup_per_bin":
+        monkeypatch.setenv("SOSGPU_STREAM_SPEC", "0")
+    elif mode == "persistent_order_scheduled":
         monkeypatch.setenv("SOSGPU_STREAM_PERSIST", "1")
     else:
         monkeypatch.setenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH", "1" if mode == "one_order_per_launch" else "3")
@@ -374,4 +379,50 @@ def test_streamed_persistent_many_bins_bitwise_equal_to_per_bin_launch(gpu_pkg, 
     rp, rb = out_p["rec"].cpu().numpy(), out_b["rec"].cpu().numpy()
     for i in range(nb):
         assert np.array_equal(rp[i, :max(no[i], 0)], rb[i, :max(no[i], 0)]), i
+    cx.close()
+
+
+@pytest.mark.parametrize("nb,n,os_nb,surf,zout,k", [(1, 13, 24, False, False, 0), (37, 13, 24, False, False, 0),
+                                                    (100, 13, 24, True, False, 0), (1, 25, 80, True, True, 0),
+                                                    (3, 25, 80, True, True, 5), (2, 41, 48, False, True, 7)])
+def test_streamed_order_parallel_form_equals_per_bin_launch(gpu_pkg, monkeypatch, nb, n, os_nb, surf, zout, k):
+    """Few bins: the Fourier orders of a bin run as independent workgroups and the stop tests are replayed afterwards (one
+    round of all orders for 1 bin, several rounds of K orders for 100 bins or with K forced).  Records of the orders a bin ran,
+    order counts, scattering-order counts and fluxes are bit for bit those of the one-workgroup-per-bin launch; ragged level
+    counts, per-bin IBORM, a malformed bin, output levels with and without surface matrices."""
+    import torch
+    import cases
+    S = gpu_pkg.synth
+    mu, w, n0 = S.gauss_angles(n - 1, 35.0)
+    al, be, ga, ze = S.hg_phase(os_nb, 0.7)
+    rng = np.random.default_rng(17)
+    b = S.ckd_bins(nb, 150 if not zout else 97, seed=21)
+    h, x, y, iborm = S.rescale_profile(b["h"], b["xdel"], b["ydel"], 0.0, 0.95, 0.95, os_nb)
+    kw = dict(ro=0.2, ifresnel=0 if surf else 1)
+    if surf:
+        kw.update(imat_surf=1, rsurf=cases._surf_matrices(n, os_nb, 5))
+    cx = gpu_pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=os_nb, **kw)
+    if zout:                                               # full-length level grids (the output level must exist in every bin)
+        bins = cx.upload_bins(h, x, y, zout=1.5, zprof=b["zprof"])
+        nbad = 0
+    else:
+        nt = rng.integers(66, 151, nb).astype(np.int32)
+        nbad = 1 if nb > 2 else 0
+        if nbad:
+            nt[nb // 2] = 0
+        bins = cx.upload_bins(h, x, y, nt=nt, iborm=rng.integers(0, os_nb + 1, nb).astype(np.int32))
+    if k:
+        monkeypatch.setenv("SOSGPU_STREAM_SPEC_K", str(k))
+    out_s = cx.solve(bins)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("SOSGPU_STREAM_SPEC", "0")
+    out_b = cx.solve(bins)
+    torch.cuda.synchronize()
+    for key in ("norders", "iglast", "flux"):
+        assert torch.equal(out_s[key], out_b[key]), key
+    no = out_b["norders"].cpu().numpy()
+    assert (no > 0).sum() == nb - nbad
+    rs, rb = out_s["rec"].cpu().numpy(), out_b["rec"].cpu().numpy()
+    for i in range(nb):
+        assert np.array_equal(rs[i, :max(no[i], 0)], rb[i, :max(no[i], 0)]), i
     cx.close()
