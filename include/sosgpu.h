@@ -106,6 +106,11 @@ int  sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_nt, const 
                      const double *d_prof, const int32_t *d_jout, const double *d_zz,
                      double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream);
 
+/* The scratch of the streamed solver (level grids beyond 64 levels) is kept by the library when a context is destroyed and
+ * handed to the next context that needs one (at most 8 buffers and 8 GiB per process): a context per wavelength would
+ * otherwise pay a 60-1000 MB hipMalloc per call.  sosgpu_trim() returns that memory to the device. */
+int  sosgpu_trim(void);
+
 /* Many wavelengths in ONE launch (hyperspectral runs, BASELINE config 5: each wavelength has only 5-100 CKD bins, a fraction
  * of the 512 workgroups the chip hosts).  The reference runs SOS_PROC once per wavelength (binding/run_sos.py:640); here the
  * bin loops SOS_PROC.F:3459-3594 of nctx wavelengths are concatenated and every bin carries the index of its wavelength.

@@ -18,7 +18,7 @@ EXPORTS = [
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
     "sosgpu_debug_phase_buffer", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
     "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce", "sosgpu_absprofile", "sosgpu_land_surface", "sosgpu_mie",
-    "sosgpu_ctx_table_entry_bytes", "sosgpu_ctx_table", "sosgpu_os_solve_multi",
+    "sosgpu_ctx_table_entry_bytes", "sosgpu_ctx_table", "sosgpu_os_solve_multi", "sosgpu_trim",
 ]
 SCAL_BASE = 10          # SOSGPU_SCAL_BASE: scalar block of sosgpu_aggregate = SCAL_BASE + N doubles
 
@@ -80,6 +80,8 @@ def lib():
         L.sosgpu_noyaux_fetch.argtypes = [vp, i32, vp]
         L.sosgpu_os_solve.restype = i32
         L.sosgpu_os_solve.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_trim.restype = i32
+        L.sosgpu_trim.argtypes = []
         L.sosgpu_ctx_table_entry_bytes.restype = C.c_size_t
         L.sosgpu_ctx_table_entry_bytes.argtypes = []
         L.sosgpu_ctx_table.restype = i32

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <vector>
 
 static thread_local int g_last_hip = 0;
@@ -204,13 +205,75 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     return SOSGPU_OK;
 }
 
+// The streamed solver's scratch outlives its context: one sos_proc call = one context (one wavelength), and a fresh hipMalloc
+// of the 60-1000 MB the order-parallel form wants costs ~9 ms per call (scripts/latency_bench.py: 1.1 ms solve, 9.2 ms first
+// call) -- more than the solve.  Released buffers wait here (per device, at most 8 of them and 8 GiB in total) for the next
+// context.  A buffer is only returned after the stream of its last solve has been synchronised.
+namespace {
+struct ScratchBuf { double *p; size_t n; int dev; };
+std::mutex g_pool_mutex;
+std::vector<ScratchBuf> g_pool;
+
+double *pool_take(int dev, size_t need, size_t *got)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); i++)
+            if (g_pool[i].dev == dev && g_pool[i].n >= need && (best < 0 || g_pool[i].n < g_pool[best].n)) best = i;
+        if (best >= 0) {
+            ScratchBuf b = g_pool[best];
+            g_pool.erase(g_pool.begin() + best);
+            *got = b.n;
+            return b.p;
+        }
+    }
+    double *p = nullptr;
+    if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) return nullptr;
+    *got = need;
+    return p;
+}
+
+void pool_give(int dev, double *p, size_t n)
+{
+    if (!p) return;
+    std::vector<double *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        g_pool.push_back({p, n, dev});
+        size_t total = 0;
+        for (const ScratchBuf &b : g_pool) total += b.n * sizeof(double);
+        while (g_pool.size() > 8 || total > ((size_t)8 << 30)) {     // oldest first
+            total -= g_pool.front().n * sizeof(double);
+            drop.push_back(g_pool.front().p);
+            g_pool.erase(g_pool.begin());
+        }
+    }
+    for (double *q : drop) (void)hipFree(q);
+}
+}   // namespace
+
+extern "C" int sosgpu_trim(void)
+{
+    std::vector<ScratchBuf> all;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        all.swap(g_pool);
+    }
+    for (const ScratchBuf &b : all) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    return SOSGPU_OK;
+}
+
 extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
 {
     if (!cx) return SOSGPU_OK;
     // teardown: nothing useful can be done with a failing free, errors are deliberately dropped
     (void)hipSetDevice(cx->device);
     for (void *p : cx->allocs) (void)hipFree(p);
-    if (cx->scratch) (void)hipFree(cx->scratch);
+    if (cx->scratch) {
+        if (cx->timed) (void)hipStreamSynchronize(cx->last_stream);     // its last solve may still be running
+        pool_give(cx->device, cx->scratch, cx->scratch_doubles);
+    }
     if (cx->prof_ng) (void)hipFree(cx->prof_ng);
     if (cx->ev0) (void)hipEventDestroy(cx->ev0);
     if (cx->ev1) (void)hipEventDestroy(cx->ev1);
@@ -347,12 +410,16 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         // + the task queues and per-bin order flags of the persistent form (ints, behind the bins' scratch)
         const size_t need = per_bin * regions + i3_doubles + (256 + (size_t)per_launch) / 2 + 1;
         if (need > cx->scratch_doubles) {
-            HIPCHK(hipDeviceSynchronize());     // a solve of this context may still be in flight on another stream
-            if (cx->scratch) (void)hipFree(cx->scratch);
+            if (cx->scratch) {
+                HIPCHK(hipDeviceSynchronize()); // a solve of this context may still be in flight on another stream
+                pool_give(cx->device, cx->scratch, cx->scratch_doubles);
+            }
             cx->scratch = nullptr;
             cx->scratch_doubles = 0;
-            HIPCHK(hipMalloc((void **)&cx->scratch, need * sizeof(double)));
-            cx->scratch_doubles = need;
+            size_t got = 0;
+            cx->scratch = pool_take(cx->device, need, &got);
+            if (!cx->scratch) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
+            cx->scratch_doubles = got;
         }
     }
     HIPCHK(hipEventRecord(cx->ev0, st));
