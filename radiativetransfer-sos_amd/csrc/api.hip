@@ -191,8 +191,12 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
         sosgpu_destroy(cx);
         return rc;
     }
+    // (hipMemset returns before the fill has run, and the fills are ordered on the NULL stream only: sosgpu_noyaux writes these
+    //  tables on the caller's stream, which -- a non-blocking stream of a host thread, run_sos.sos_proc_many -- does not wait for
+    //  the null stream.  Without the synchronisation the fill could land on top of the packed molecular operator.)
     if (hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double)) != hipSuccess ||
-        hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double)) != hipSuccess) {
+        hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double)) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
         g_last_hip = (int)hipGetLastError();
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;
@@ -332,6 +336,7 @@ extern "C" int sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf)
         if (rc) return rc;
     }
     dim3 grid((unsigned)((std::max(per, (size_t)3 * cx->d.n) + 255) / 256), (unsigned)S1);
+    HIPCHK(hipDeviceSynchronize());          // d_rsurf may still be in the making on any stream of the caller
     k_pack_ground<<<grid, 256>>>(cx->d, d_rsurf, cx->gnd_op, cx->gnd_dir);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());          // the caller may release or overwrite d_rsurf afterwards
@@ -391,7 +396,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (const char *e = getenv("SOSGPU_SCRATCH_GIB")) { const long v = atol(e); if (v > 0) gib = (size_t)v; }
         const size_t cap = (gib << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
-        // Few bins (a band of one wavelength): the order-parallel form -- K Fourier orders of every bin at a time, each in a
+        // Few bins (a band of one wavelength): the order-parallel form -- up to 32 Fourier orders of every bin at a time, each in a
         // work region of its own, so that the band fills ~1024 workgroup slots (sos_stream.hip; SOSGPU_STREAM_SPEC=0 turns it
         // off, SOSGPU_STREAM_SPEC_MAXBINS moves the limit).  A single bin takes 11 ms as one workgroup, ~1.5 ms this way.
         int spec_max = 128;
@@ -401,7 +406,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (const char *e = getenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH")) { if (atoi(e) > 0) spec_max = 0; }
         const int s1n = cx->d.smax + 1;
         if (!table && nb <= spec_max && s1n > 1) {
-            spec_k = std::min(s1n, std::max(2, 1024 / nb));
+            spec_k = std::min(std::min(s1n, 32), std::max(2, 1024 / nb));     // the first round; later rounds run half as many
             if (const char *e = getenv("SOSGPU_STREAM_SPEC_K")) spec_k = std::min(s1n, std::max(1, atoi(e)));   // (tests)
             if ((size_t)nb * spec_k * per_bin > cap) spec_k = 0;
         }
@@ -422,6 +427,9 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
             cx->scratch_doubles = got;
         }
     }
+    // (The scratch is reused from solve to solve and from context to context -- pool above -- without being cleared: the streamed
+    //  kernel initialises what it reads; the pad levels and pad columns it stages along with a chunk feed columns / rows of
+    //  the contraction that are never stored.)
     HIPCHK(hipEventRecord(cx->ev0, st));
     const int S1 = cx->d.smax + 1, W = cx->d.w;
     for (int b0 = 0; b0 < nb; b0 += per_launch) {
@@ -444,8 +452,10 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
             bn.spec_k = -spec_k; bn.s_begin = 0; bn.s_end = 0;
             rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
             bn.spec_k = spec_k;
-            for (int s0 = 0; s0 < S1 && rc == 0; s0 += spec_k) {
-                bn.s_begin = s0; bn.s_end = std::min(S1, s0 + spec_k);
+            // (a series typically ends after 25-50 of its up to 81 orders: 32 + 16 + ... wastes less than all at once, and a
+            //  launch whose bins have all stopped costs a few microseconds)
+            for (int s0 = 0, kr = spec_k; s0 < S1 && rc == 0; s0 += kr, kr = std::max(1, spec_k / 2)) {
+                bn.s_begin = s0; bn.s_end = std::min(S1, s0 + kr);
                 rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
                 if (rc == 0) rc = launch_sos_stream_replay(cx->d, bn, bn.s_begin, bn.s_end, st, &g_last_hip);
             }
