@@ -361,6 +361,7 @@ extern "C" int sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out)
     const size_t cnt = (size_t)6 * cx->d.w * cx->d.w + 3 * cx->d.w;
     double *tmp = nullptr;
     HIPCHK(hipMalloc((void **)&tmp, cnt * sizeof(double)));
+    HIPCHK(hipDeviceSynchronize());          // sosgpu_noyaux may still be running on a stream the null stream does not wait for
     launch_noyaux_fetch(cx->d, is, tmp, nullptr);
     hipError_t e = hipMemcpy(out, tmp, cnt * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
