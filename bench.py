@@ -236,6 +236,32 @@ def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g):
     return res
 
 
+def small_band_latency(pkg, torch, g, nbins=25):
+    """One wavelength's band as a per-call user has it: `nbins` CKD bins on real level grids, ONE solve + aggregate, wall clock
+    (the order-parallel form of the streamed solver: the Fourier orders of a bin as independent workgroups)."""
+    S = pkg.synth
+    mu, w, n0 = S.gauss_angles(40, 35.0)
+    al, be, ga, ze = S.hg_phase(80, g)
+    cx = pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=80, ro=0.1)
+    alt, tabs = realistic_columns(nbins)
+    bins = cx.make_profiles(nbins, 0.0948, 8.0, 0.3, 2.0, alt, tabs, piz=0.95, piztr=0.95)
+    aik = torch.full((nbins,), 1.0 / nbins, dtype=torch.float64, device=cx.device)
+    out = cx.alloc_outputs(nbins)
+    ts = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cx.solve(bins, out)
+        cx.aggregate(out, aik, scal=bins["scal"])
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    nt = bins["nt"].cpu().numpy()
+    cx.close()
+    return dict(bins=nbins, ms_per_solve=1e3 * min(ts[1:]), value=nbins / min(ts[1:]), unit="bins/s",
+                config="one band of %d bins, level grids NT %d...%d, N = 41, OS_NB = 80: solve + aggregate, wall clock, min of 5"
+                       % (nbins, nt.min(), nt.max()))
+
+
 def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup, args, base):
     """One measurement of the headline workload with `nbins` CKD bins per GPU and step: returns (result dict, workload, per-bin
     Fourier-order counts)."""
@@ -349,6 +375,7 @@ def main():
                                      bins_per_gpu=SMALL_BATCH, roofline_frac=sm["roofline"]["frac"],
                                      kernel_ms=sm["roofline"]["kernel_ms"])
         res["realistic_mix"] = run_realistic(pkg, torch, dist, world, rank, SMALL_BATCH, max(2, args.steps // 5), 1, args.g)
+        res["small_band"] = small_band_latency(pkg, torch, args.g)
     if rank == 0:
         res["config"]["mean_fourier_orders"] = float(nord.mean())
         if world == 1 and not args.no_cpu:
