@@ -233,6 +233,7 @@ double *pool_take(int dev, size_t need, size_t *got)
         }
     }
     double *p = nullptr;
+    if (getenv("SOSGPU_DEBUG_POOL")) fprintf(stderr, "[sosgpu pool] hipMalloc %.1f MB\n", need * 8e-6);
     if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) return nullptr;
     *got = need;
     return p;
@@ -253,6 +254,7 @@ void pool_give(int dev, double *p, size_t n)
             g_pool.erase(g_pool.begin());
         }
     }
+    if (!drop.empty() && getenv("SOSGPU_DEBUG_POOL")) fprintf(stderr, "[sosgpu pool] hipFree of %zu buffer(s)\n", drop.size());
     for (double *q : drop) (void)hipFree(q);
 }
 }   // namespace
@@ -397,7 +399,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (const char *e = getenv("SOSGPU_SCRATCH_GIB")) { const long v = atol(e); if (v > 0) gib = (size_t)v; }
         const size_t cap = (gib << 30) / sizeof(double);
         per_launch = (int)std::min<size_t>((size_t)nb, std::max<size_t>(1, cap / per_bin));
-        // Few bins (a band of one wavelength): the order-parallel form -- up to 32 Fourier orders of every bin at a time, each in a
+        // Few bins (a band of one wavelength): the order-parallel form -- up to 48 Fourier orders of every bin at a time, each in a
         // work region of its own, so that the band fills ~1024 workgroup slots (sos_stream.hip; SOSGPU_STREAM_SPEC=0 turns it
         // off, SOSGPU_STREAM_SPEC_MAXBINS moves the limit).  A single bin takes 11 ms as one workgroup, ~1.5 ms this way.
         int spec_max = 128;
@@ -407,7 +409,10 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (const char *e = getenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH")) { if (atoi(e) > 0) spec_max = 0; }
         const int s1n = cx->d.smax + 1;
         if (!table && nb <= spec_max && s1n > 1) {
-            spec_k = std::min(std::min(s1n, 32), std::max(2, 1024 / nb));     // the first round; later rounds run half as many
+            // first round: 48 orders (a series typically ends after 25-50 of its up to 81), 24 above 40 bins; later rounds run
+            // half as many.  Measured (profiles/r02_sos_proc_latency.txt): the number of rounds is what costs, not the tasks
+            // beyond the chip's 512 workgroup slots.
+            spec_k = std::min(s1n, nb <= 40 ? 48 : 24);
             if (const char *e = getenv("SOSGPU_STREAM_SPEC_K")) spec_k = std::min(s1n, std::max(1, atoi(e)));   // (tests)
             if ((size_t)nb * spec_k * per_bin > cap) spec_k = 0;
         }
