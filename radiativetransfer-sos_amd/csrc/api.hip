@@ -391,8 +391,8 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
     int rc = sos_os_variant(cx->d.n, nt_max, &nw, &rtw, &ct, &lds, &big);
     if (rc) return rc;
     int per_launch = nb, spec_k = 0;
-    const int lpb = sos_round_up(lp, 32);
-    const size_t per_bin = big ? sos_stream_scratch_doubles(cx->d.n, lpb) : 0;
+    int lpb = sos_round_up(lp, 32);
+    size_t per_bin = big ? sos_stream_scratch_doubles(cx->d.n, lpb) : 0;
     if (big) {
         // scratch budget: 64 GiB of the 288 GB (a launch covers ~40 000 bins at 608 levels; SOSGPU_SCRATCH_GIB overrides it)
         size_t gib = 64;
@@ -413,8 +413,23 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
             // half as many.  Measured (profiles/r02_sos_proc_latency.txt): the number of rounds is what costs, not the tasks
             // beyond the chip's 512 workgroup slots.
             spec_k = std::min(s1n, nb <= 40 ? 48 : 24);
+            // The work regions are laid out for the batch's own level count, not for the padded row length `lp` of the caller
+            // (608 for profiles made by sosgpu_profile): the few NT come to the host -- one small copy behind the work already
+            // queued on the stream, which this latency-bound form has to wait for anyway.
+            std::vector<int32_t> h_nt((size_t)nb);
+            HIPCHK(hipMemcpyAsync(h_nt.data(), d_nt, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            int ntm = 1;
+            for (int b = 0; b < nb; b++) if (h_nt[b] < lp) ntm = std::max(ntm, (int)h_nt[b]);    // (malformed bins are flagged by the kernel)
+            lpb = std::min(lpb, sos_round_up(ntm + 1, 32));
+            per_bin = sos_stream_scratch_doubles(cx->d.n, lpb);
+            // at most 4 GiB of work regions (128 bins x 24 orders at 600 levels need 4.6): beyond, fewer orders per round
+            const size_t soft = ((size_t)4 << 30) / sizeof(double);
+            const size_t fit = soft / ((size_t)nb * per_bin);
+            if (fit < (size_t)spec_k) spec_k = std::max(std::min(spec_k, 8), (int)fit);
             if (const char *e = getenv("SOSGPU_STREAM_SPEC_K")) spec_k = std::min(s1n, std::max(1, atoi(e)));   // (tests)
             if ((size_t)nb * spec_k * per_bin > cap) spec_k = 0;
+            if (!spec_k) { lpb = sos_round_up(lp, 32); per_bin = sos_stream_scratch_doubles(cx->d.n, lpb); }
         }
         const size_t regions = spec_k ? (size_t)nb * spec_k : (size_t)per_launch;
         const size_t i3_doubles = spec_k ? (size_t)nb * s1n * sos_stream_threads(cx->d.n) : 0;
@@ -455,14 +470,15 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (big && spec_k) {
             // order-parallel form: set-up launch, then rounds of (K order tasks per bin, replay of their stop tests)
             bn.spec_i3 = cx->scratch + per_bin * (size_t)nb * spec_k;
+            const int nt_max_r = lpb - 1;              // level capacity of the regions (>= every valid NT of the batch)
             bn.spec_k = -spec_k; bn.s_begin = 0; bn.s_end = 0;
-            rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
+            rc = launch_sos_stream(cx->d, bn, nt_max_r, st, &g_last_hip);
             bn.spec_k = spec_k;
             // (a series typically ends after 25-50 of its up to 81 orders: 32 + 16 + ... wastes less than all at once, and a
             //  launch whose bins have all stopped costs a few microseconds)
             for (int s0 = 0, kr = spec_k; s0 < S1 && rc == 0; s0 += kr, kr = std::max(1, spec_k / 2)) {
                 bn.s_begin = s0; bn.s_end = std::min(S1, s0 + kr);
-                rc = launch_sos_stream(cx->d, bn, nt_max, st, &g_last_hip);
+                rc = launch_sos_stream(cx->d, bn, nt_max_r, st, &g_last_hip);
                 if (rc == 0) rc = launch_sos_stream_replay(cx->d, bn, bn.s_begin, bn.s_end, st, &g_last_hip);
             }
         } else if (big) {
