@@ -374,7 +374,7 @@ def main():
             res["batch_4096"] = dict(value=sm["value"], unit="bins/s", ms_per_step=sm["ms_per_step"], steps=sm["steps"],
                                      bins_per_gpu=SMALL_BATCH, roofline_frac=sm["roofline"]["frac"],
                                      kernel_ms=sm["roofline"]["kernel_ms"])
-        res["realistic_mix"] = run_realistic(pkg, torch, dist, world, rank, SMALL_BATCH, max(2, args.steps // 5), 1, args.g)
+        res["realistic_mix"] = run_realistic(pkg, torch, dist, world, rank, SMALL_BATCH, max(3, args.steps // 3), 2, args.g)
         res["small_band"] = small_band_latency(pkg, torch, args.g)
     if rank == 0:
         res["config"]["mean_fourier_orders"] = float(nord.mean())
