@@ -1038,6 +1038,9 @@ def sos_proc_many(kwargs_list, n_workers=8, device=0):
     capi.lib()                                             # loaded once, before the threads
     if not kwargs_list:
         return []
+    if _dist_rank_world()[1] > 1:
+        raise SosProcError("sos_proc_many: with torch.distributed initialised every sos_proc call is a collective over the "
+                           "ranks (the band's bins are sharded) -- issue the calls one after the other")
     dev = torch.device("cuda", device)
     nw = max(1, min(int(n_workers), len(kwargs_list)))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]

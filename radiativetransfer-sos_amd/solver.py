@@ -332,6 +332,12 @@ class SosContext:
             pass
 
 
+def release_scratch():
+    """Return the scratch buffers the library keeps from destroyed contexts (streamed solver; at most 8 GiB) to the device
+    (sosgpu_trim)."""
+    capi.check(capi.lib().sosgpu_trim(), "sosgpu_trim")
+
+
 class ContextTable:
     """Device-resident table of wavelength contexts (sosgpu_ctx_table) for solve_spectrum: ONE kernel launch then covers the
     bins of all these wavelengths.  The contexts must agree in N, iborm_max and IMAT_SURF; the table stays valid while they
