@@ -120,11 +120,13 @@ int  sosgpu_trim(void);
  *                      stays valid until one of them is destroyed or has sosgpu_set_surface_matrices called again.
  *   sosgpu_os_solve_multi   sosgpu_os_solve with d_ctx_of_bin[nb] (int32, 0..nctx-1): bin b is solved with the operators of
  *                      table entry d_ctx_of_bin[b].  `cx` is any context of the table (it provides the variant selection, the
- *                      streamed variant's scratch and the timing events).  All other arguments as sosgpu_os_solve; feed
- *                      sosgpu_aggregate with one segment per wavelength. */
+ *                      streamed variant's scratch and the timing events).  d_order[nb] (int32, a permutation of 0..nb-1) or
+ *                      NULL: workgroup i solves bin d_order[i] -- workgroups start in index order, so listing the costliest
+ *                      bins first shortens the tail of the launch while the bins stay grouped by wavelength in memory.
+ *                      All other arguments as sosgpu_os_solve; feed sosgpu_aggregate with one segment per wavelength. */
 size_t sosgpu_ctx_table_entry_bytes(void);
 int  sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table);
-int  sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, int nb, int lp,
+int  sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, const int32_t *d_order, int nb, int lp,
                            const int32_t *d_nt, const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout,
                            const double *d_zz, double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux,
                            void *stream);

@@ -372,7 +372,7 @@ extern "C" int sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out)
 }
 
 // sosgpu_os_solve (table == null) and sosgpu_os_solve_multi (per-bin contexts from a device table)
-static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_ctx_of_bin, int nb, int lp, const int32_t *d_nt,
+static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_ctx_of_bin, const int32_t *d_order, int nb, int lp, const int32_t *d_nt,
                          const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout, const double *d_zz,
                          double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream)
 {
@@ -463,6 +463,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         bn.scratch = big ? cx->scratch : nullptr; bn.scr_stride = per_bin; bn.lpb = lpb;
         bn.phase = cx->phase ? cx->phase + (size_t)b0 * 8 : nullptr;
         bn.ctxs = table; bn.ctx_of_bin = table ? d_ctx_of_bin + b0 : nullptr;
+        bn.order = (table && per_launch >= nb) ? d_order : nullptr;      // (a split batch keeps its given order)
         bn.queue = bn.qflag = nullptr; bn.q_tail = -1;
         bn.spec_k = 0; bn.spec_i3 = nullptr;
         if (const char *e = getenv("SOSGPU_STREAM_QTAIL")) bn.q_tail = atoi(e);
@@ -521,8 +522,8 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
                                const double *d_prof, const int32_t *d_jout, const double *d_zz,
                                double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux, void *stream)
 {
-    return os_solve_impl(cx, nullptr, nullptr, nb, lp, d_nt, d_iborm, d_prof, d_jout, d_zz, d_rec, d_norders, d_iglast, d_flux,
-                         stream);
+    return os_solve_impl(cx, nullptr, nullptr, nullptr, nb, lp, d_nt, d_iborm, d_prof, d_jout, d_zz, d_rec, d_norders, d_iglast,
+                         d_flux, stream);
 }
 
 extern "C" size_t sosgpu_ctx_table_entry_bytes(void) { return sizeof(SosDev); }
@@ -547,14 +548,15 @@ extern "C" int sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table
     return SOSGPU_OK;
 }
 
-extern "C" int sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, int nb, int lp,
+extern "C" int sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, const int32_t *d_order,
+                                     int nb, int lp,
                                      const int32_t *d_nt, const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout,
                                      const double *d_zz, double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux,
                                      void *stream)
 {
     if (!d_table || !d_ctx_of_bin) return SOSGPU_E_ARG;
-    return os_solve_impl(cx, static_cast<const SosDev *>(d_table), d_ctx_of_bin, nb, lp, d_nt, d_iborm, d_prof, d_jout, d_zz,
-                         d_rec, d_norders, d_iglast, d_flux, stream);
+    return os_solve_impl(cx, static_cast<const SosDev *>(d_table), d_ctx_of_bin, d_order, nb, lp, d_nt, d_iborm, d_prof, d_jout,
+                         d_zz, d_rec, d_norders, d_iglast, d_flux, stream);
 }
 
 extern "C" int sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms)

@@ -83,6 +83,8 @@ struct SosBins {
     // of a device-resident context table instead of the kernel argument; null otherwise
     const SosDev *ctxs;
     const int32_t *ctx_of_bin;
+    const int32_t *order;        // multi-wavelength launches: workgroup i solves bin order[i] (costliest bins first: workgroups
+                                 // are dispatched in index order and the bins stay grouped by wavelength for the aggregate), or null
 };
 
 // The kernels read the wavelength context through `cx`: the by-value kernel argument, or -- SOS_MULTI builds -- the bin's
@@ -91,9 +93,11 @@ struct SosBins {
 typedef const __attribute__((address_space(4))) SosDev SosDevK;
 typedef const __attribute__((address_space(4))) SosBins SosBinsK;
 #ifdef SOS_MULTI
+#define SOS_BIN_INDEX(bn) ((bn).order ? __builtin_amdgcn_readfirstlane((bn).order[blockIdx.x]) : (int)blockIdx.x)
 #define SOS_BIND_CTX(cx, arg, bn)                                                                                   \
-    const SosDevK &cx = *(const SosDevK *)(unsigned long long)((bn).ctxs + __builtin_amdgcn_readfirstlane((bn).ctx_of_bin[blockIdx.x]))
+    const SosDevK &cx = *(const SosDevK *)(unsigned long long)((bn).ctxs + __builtin_amdgcn_readfirstlane((bn).ctx_of_bin[SOS_BIN_INDEX(bn)]))
 #else
+#define SOS_BIN_INDEX(bn) ((int)blockIdx.x)
 #define SOS_BIND_CTX(cx, arg, bn) const SosDev &cx = arg
 #endif
 // offset of the second kernel argument (SosBins) behind the first (SosDev) in the kernarg segment: both 8-byte aligned

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
     double *pcb = cbuf + (lane & 15) * FS + (cx.prow >= 0 ? cx.prow : 0) + (lane >> 4);    // see gemm_source (fold)
 
     {   // one workgroup = one bin (grid = nb): no bin loop, so per-bin constants are not kept live elsewhere
-        const int b = blockIdx.x;
+        const int b = SOS_BIN_INDEX(bn);
         const int nt = uniform_i32(bn.nt[b]);
         const int iborm = uniform_i32(bn.iborm[b]);
         const int jout = ZO ? uniform_i32(bn.jout ? bn.jout[b] : 0) : 0;

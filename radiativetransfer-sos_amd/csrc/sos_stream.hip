@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         else if (K > 0) {
             const int b = blockIdx.x / K, j = blockIdx.x - b * K;
             if (bn.s_begin + j < bn.s_end) run_task(b, bn.s_begin + j, bn.s_begin + j + 1, (size_t)b * K, (size_t)b * K + j, true);
-        } else run_task(blockIdx.x, bn.s_begin, bn.s_end, blockIdx.x, blockIdx.x, false);
+        } else { const int b = SOS_BIN_INDEX(bn); run_task(b, bn.s_begin, bn.s_end, b, b, false); }
         return;
     }
     // ---- persistent form: order-scheduled tasks ---------------------------------------------------------------------------

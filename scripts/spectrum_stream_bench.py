@@ -40,5 +40,19 @@ for mode in ("1", "0", "1", "0"):
     same = all(torch.equal(a[0], b[0]) for a, b in zip(got, ref))
     print("%d wavelengths x %d bins (NT 117..~400), 16 streams, order-parallel %s: %7.0f bins/s  (%.1f ms per spectrum)  same bands: %s"
           % (W, B, "on " if mode == "1" else "off", W * B / dt, dt * 1e3, same), flush=True)
+# the whole spectrum in ONE launch (per-bin context table, one workgroup per bin) + one segmented aggregate
+table = pkg.solver.ContextTable([it[0] for it in items])
+bins_all, cob, seg = pkg.solver.concat_bins([it[1] for it in items])
+aik_all = torch.cat([it[2] for it in items])
+out_all = items[0][0].alloc_outputs(bins_all["nb"], zero=False)
+got = pkg.solver.solve_spectrum(table, bins_all, cob, seg, aik_all, out=out_all); torch.cuda.synchronize()
+same = all(torch.equal(got[0][i], ref[i][0][0]) for i in range(W))
+t0 = time.perf_counter()
+for _ in range(2):
+    pkg.solver.solve_spectrum(table, bins_all, cob, seg, aik_all, out=out_all)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 2
+print("%d wavelengths x %d bins, ONE launch (solve_spectrum):                  %7.0f bins/s  (%.1f ms per spectrum)  same bands: %s"
+      % (W, B, W * B / dt, dt * 1e3, same), flush=True)
 for cx, _, _ in items:
     cx.close()
