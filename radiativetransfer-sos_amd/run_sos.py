@@ -25,6 +25,7 @@ lost in an `intent(in)` `ier`; `gen_sos_output` imports `ceil` and uses `and` (t
 files are written only when `-SOS_Main.ResRoot` is given (RESROOT/SOS/SOS_Result.bin, the -SOS.Trans / -SOS.Flux files).
 """
 import collections
+import functools
 import math
 import os
 import threading
@@ -214,6 +215,13 @@ def write_used_angles(path, mu, ga, n0, ind_ang, nb_gauss, tetas, os_nb, os_ns, 
 
 
 def sos_gauss(nb_gauss):
+    """(cached per order: the Newton iterations cost 2 ms of every call otherwise; fresh arrays are returned)"""
+    mu, wt = _sos_gauss_nodes(int(nb_gauss))
+    return np.array(mu), np.array(wt)
+
+
+@functools.lru_cache(maxsize=32)
+def _sos_gauss_nodes(nb_gauss):
     """SOS_GAUSS (SOS_ANGLES.F:1022-1103) for MM = nb_gauss + 1: the positive nodes and weights of the 2 nb_gauss-point
     Gauss-Legendre rule, ascending in the cosine -- the reference's own Newton iteration (asymptotic start, three-term
     recurrence, stop at |dx| <= 1e-15), statement for statement, so that the D21.14 digits of the angle files agree in
@@ -245,8 +253,8 @@ def sos_gauss(nb_gauss):
                 break
             x = xi
     # R(I), I = 1..MM-1, descend from the largest node: AMU(K = MM - I) -> ascending cosines for K = 1..nb_gauss
-    mu = np.array([r[i] for i in range(nb_gauss)][::-1])
-    wt = np.array([w[i] for i in range(nb_gauss)][::-1])
+    mu = tuple([r[i] for i in range(nb_gauss)][::-1])
+    wt = tuple([w[i] for i in range(nb_gauss)][::-1])
     return mu, wt
 
 
