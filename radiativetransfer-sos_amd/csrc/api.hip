@@ -486,7 +486,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
             // The streamed kernel can run `opl` Fourier orders of every bin per launch (order-synchronous launches: every
             // workgroup then streams the same source operator).  Measured on the realistic mix (profiles/r02_stream_experiments.txt):
             // 1 order per launch 21.1k bins/s, all orders in one launch 21.9k -- the operator stream is not what binds, so one
-            // launch is the default; SOSGPU_STREAM_ORDERS_PER_LAUNCH = n selects n orders per launch (tests cover both).
+            // launch is the default for large batches; SOSGPU_STREAM_ORDERS_PER_LAUNCH = n selects n orders per launch (tests cover both).
             int opl = 0;
             if (const char *e = getenv("SOSGPU_STREAM_ORDERS_PER_LAUNCH")) opl = atoi(e);
             if (opl <= 0) opl = S1;

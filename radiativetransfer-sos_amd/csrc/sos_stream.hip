@@ -22,6 +22,11 @@
 // loaded.  Algebraically the reference recurrence X_i = t X_{i+1} + p S_i + w S_{i+1}; rounding differs at 1e-16 of the field.
 // Scratch traffic per scattering order: the field once in and once out (the field-in-HBM variant of round 1 moved it three
 // times, with the B operands and both sweeps latency-bound on global memory).
+//
+// Launch forms (api.hip, os_solve_impl): one workgroup per bin running all its Fourier orders (large batches); the
+// ORDER-PARALLEL form for few bins -- one workgroup per (bin, Fourier order), the stop tests replayed by k_sos_stream_replay
+// (SosBins::spec_k); a persistent launch taking (order, bin) tasks from per-XCD queues (PERSIST, opt-in); order-synchronous
+// launches (SosBins::s_begin / s_end, opt-in).  All of them run the same task body, run_task.
 #include <algorithm>
 #include <cstdlib>
 #include "sos_dev.h"
