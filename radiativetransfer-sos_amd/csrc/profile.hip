@@ -114,6 +114,65 @@ __device__ double disc(double dt, double ta, double ha, double tr, double hr, co
     return zmoy;
 }
 
+// SOS_DISC by the 64 lanes of a wavefront: the same bisection, six of its steps per evaluation.  The bisection visits a path
+// in the binary tree of brackets below [zmin, zmax]; lane n = 1..63 takes heap node n of the six-level subtree under the
+// current bracket, walks to it with the reference's own midpoint statement (so its ZMOY is bit for bit the one the serial loop
+// would form on that path), and evaluates the optical depth there -- the 2 exponentials and the gas-profile lookup that make a
+// serial step ~1000 cycles.  The comparison and stop results of all nodes are two wave masks; the path through them is resolved
+// with scalar bit tests.  25-30 serial evaluations per level become 5 rounds.
+__device__ __forceinline__ double lane_read(double v, int lane)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+__device__ double disc_wave(double dt, double ta, double ha, double tr, double hr, const GasProf &g, double tim1,
+                            double zmax_init, double tg_zlim, double zlim)
+{
+    const double ti = tim1 + dt;
+    const int lane = threadIdx.x & 63;
+    const int node = lane ? lane : 1;                        // lane 0 shadows the root (its results are not used)
+    const int depth = 31 - __builtin_clz(node);              // 0..5
+    double zmax = zmax_init, zmin = zlim, zres = 0.;
+    for (int round = 0; round < 683; round++) {              // 683 x 6 >= the 4096 evaluations of the serial guard
+        double lo = zmin, hi = zmax, zmoy = (hi + lo) / 2.;
+        for (int k = depth - 1; k >= 0; --k) {               // the path to this lane's node: bit set = "ZMIN = ZMOY" was taken
+            if ((node >> k) & 1) lo = zmoy; else hi = zmoy;
+            zmoy = (hi + lo) / 2.;
+        }
+        double tg;
+        if (tg_zlim > 0.0) {
+            const int j = g.seg(zmoy);
+            double zz;
+            if (zmoy > g.alt[0]) zz = 0;
+            else zz = (zmoy - g.alt[j - 2]) / (g.alt[j - 1] - g.alt[j - 2]);
+            tg = (1 - zz) * g.tab[j - 2] + zz * g.tab[j - 1];
+        } else tg = 0.0;
+        const double tzmoy = ta * exp(-zmoy / ha) + tr * exp(-zmoy / hr) + tg;
+        const double xd = fabs(ti - tzmoy);
+        const bool stop = xd < (double).000001f || zmoy == 0.0;
+        const bool up = (ti - tzmoy) < 0.0;                  // ZMIN = ZMOY
+        const unsigned long long sm = __ballot(stop), um = __ballot(up);
+        int n = 1;
+        bool found = false;
+        for (int d = 0; d < 6; d++) {
+            if ((sm >> n) & 1ull) { found = true; break; }
+            if (d == 5) break;
+            n = 2 * n + (int)((um >> n) & 1ull);
+        }
+        n = __builtin_amdgcn_readfirstlane(n);
+        zres = lane_read(zmoy, n);
+        if (found) return zres;
+        // six steps taken without a stop: the bracket below node n (a node of the last level)
+        const double lo_n = lane_read(lo, n), hi_n = lane_read(hi, n);
+        if ((um >> n) & 1ull) { zmin = zres; zmax = hi_n; } else { zmin = lo_n; zmax = zres; }
+    }
+    return zres;
+}
+
 }  // namespace
 
 // One thread per bin, `bpw` bins per wavefront.  The work of a bin is a long serial chain (latency-bound) and very ragged
@@ -121,10 +180,15 @@ __device__ double disc(double dt, double ta, double ha, double tr, double hr, co
 // batch spreads over all 1024 SIMDs and a wave only waits for the slowest of its few bins.
 // prof[b][3][lp] <- H, XDEL, YDEL (after the rescale), zprof[b][lp], nt, iborm, jout, zz,
 // scal[b][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT}; nt[b] = -1 flags a profile that does not fit (IER of the reference).
+// WAVE = true (the form launched): ONE WAVEFRONT per bin.  All 64 lanes run the bin's level loop in lockstep on the same
+// values (stores of one instruction go to one address) and share the work where the time is: SOS_DISC (disc_wave).  A single
+// bin takes 6.5-9.7 ms with one lane (most of the latency of a 25-bin sos_proc call) and 2.3-2.9 ms this way; 4096 bins 24.8 -> 3.8-5.3 ms.
+template <bool WAVE>
 __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
 {
-    if ((int)threadIdx.x >= bpw) return;          // no barrier below: every thread only touches its own LDS slice
-    const int b = blockIdx.x * bpw + threadIdx.x;
+    if (!WAVE && (int)threadIdx.x >= bpw) return; // no barrier below: every thread only touches its own LDS slice
+    const int b = WAVE ? (int)blockIdx.x : blockIdx.x * bpw + threadIdx.x;
+    const int slot = WAVE ? 0 : (int)threadIdx.x;
     if (b >= a.nb) return;
     const double TCOUCHE = (double)0.005f, T_FIRST = (double)0.0002f, DELTA_Z = (double)0.05f, DZ = (double)0.001f;
     const double TAUABS_MAX = 1.5, TOA = 120.0;
@@ -134,12 +198,12 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
     double *Z = a.zprof + (size_t)b * a.lp;
     // the bin's absorption profile is read thousands of times: keep it (and the altitude grid) in LDS
     __shared__ double s_alt[SOS_PROF_NBLEV_MAX];
-    __shared__ double s_tab[64][SOS_PROF_NBLEV_MAX + 1];     // +1: odd stride, lanes on different banks
+    __shared__ double s_tab[WAVE ? 1 : 64][SOS_PROF_NBLEV_MAX + 1];     // +1: odd stride, lanes on different banks
     GasProf g;
     g.n = a.nblev; g.alt = s_alt; g.tab = nullptr;
     if (a.tabs) {
-        for (int i = 0; i < a.nblev; i++) { s_tab[threadIdx.x][i] = a.tabs[(size_t)b * a.nblev + i]; s_alt[i] = a.altabs[i]; }
-        g.tab = s_tab[threadIdx.x];
+        for (int i = 0; i < a.nblev; i++) { s_tab[slot][i] = a.tabs[(size_t)b * a.nblev + i]; s_alt[i] = a.altabs[i]; }
+        g.tab = s_tab[slot];
     }
     const double tgtot = g.tab ? g.tab[a.nblev - 1] : 0.0;
     int nt;
@@ -196,7 +260,8 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
                 }
                 ing = 1;
             } else {
-                z = disc(t_layer, ta, ha, tr, hr, g, h_p, Z[1], tg_zlim, zlim);
+                z = WAVE ? disc_wave(t_layer, ta, ha, tr, hr, g, h_p, Z[1], tg_zlim, zlim)
+                         : disc(t_layer, ta, ha, tr, hr, g, h_p, Z[1], tg_zlim, zlim);
             }
             if (z <= zing) { z = zing; ing = ing + 1; zing = a.z_ng[min(ing, a.nt_ng)]; }
             else if ((z - zing) <= DZ) { ing = ing + 1; zing = a.z_ng[min(ing, a.nt_ng)]; }
@@ -260,7 +325,12 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
         return;
     }
     // PROFIL file round trip (SOS_PROFIL.F:1084 format 20 -> SOS.F:515 format 70)
-    for (int i = 0; i <= nt; i++) { Z[i] = rt_f10_5(Z[i]); H[i] = rt_e15_8(H[i]); XD[i] = rt_e15_8(XD[i]); YD[i] = rt_e15_8(YD[i]); }
+    // (WAVE: the independent per-level passes are dealt to the lanes, level i to lane i mod 64; the barrier of the one-wave
+    //  block makes the stores of the other lanes visible to the serial passes that follow)
+    const int i0 = WAVE ? (int)(threadIdx.x & 63) : 0, di = WAVE ? 64 : 1;
+    if (WAVE) __syncthreads();
+    for (int i = i0; i <= nt; i += di) { Z[i] = rt_f10_5(Z[i]); H[i] = rt_e15_8(H[i]); XD[i] = rt_e15_8(XD[i]); YD[i] = rt_e15_8(YD[i]); }
+    if (WAVE) __syncthreads();
     const double ttot_vrai = H[nt];
     // truncation rescale (SOS.F:521-543) and IBORM (:549-550)
     bool lta = true;
@@ -280,8 +350,11 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
             htr_p = htr;
         }
     }
-    for (int i = 0; i <= nt; i++) { XD[i] = XD[i] * a.piztr; if (XD[i] != 0.) lta = false; }
-    for (int i = nt + 1; i < a.lp; i++) { H[i] = 0.; XD[i] = 0.; YD[i] = 0.; Z[i] = 0.; }
+    if (WAVE) __syncthreads();
+    for (int i = i0; i <= nt; i += di) { XD[i] = XD[i] * a.piztr; if (XD[i] != 0.) lta = false; }
+    if (WAVE) lta = !__any(!lta);
+    for (int i = nt + 1 + i0; i < a.lp; i += di) { H[i] = 0.; XD[i] = 0.; YD[i] = 0.; Z[i] = 0.; }
+    if (WAVE) __syncthreads();
     a.nt[b] = nt;
     a.iborm[b] = lta ? min(2, a.smax) : a.smax;
     double tauout = H[0];
@@ -304,9 +377,12 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
 
 void launch_profile(const ProfileArgs &a, hipStream_t st)
 {
-    // about 2048 wavefronts (2 per SIMD) whatever the batch size
-    const int bpw = std::min(64, std::max(1, (a.nb + 2047) / 2048));
-    k_profile<<<(a.nb + bpw - 1) / bpw, 64, 0, st>>>(a, bpw);
+    // one wavefront per bin; SOSGPU_PROFILE_LANES=1: the one-lane-per-bin form (about 2048 wavefronts whatever the batch size)
+    const char *e = getenv("SOSGPU_PROFILE_LANES");
+    if (e && atoi(e)) {
+        const int bpw = std::min(64, std::max(1, (a.nb + 2047) / 2048));
+        k_profile<false><<<(a.nb + bpw - 1) / bpw, 64, 0, st>>>(a, bpw);
+    } else k_profile<true><<<a.nb, 64, 0, st>>>(a, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
