@@ -925,11 +925,19 @@ def sos_proc(aer_phase=None, device=0, **kw):
     try:
         # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device, one fused solve, one aggregate
         band_sharded = False                          # True: every rank holds a slice of the band and the partials are all-reduced
-        if not use_gas:
-            if iprofil == 1:
-                h, xdel, ydel, zprof = profile_nogas(tr, p["hr"], ta, ha)
-            else:
-                h, xdel, ydel, zprof = profile_layer(tr, p["hr"], ta, float(p["zmin"]), float(p["zmax"]))
+        if not use_gas and iprofil == 1:
+            # the single no-gas profile of the wavelength: SOS_PROFILE, the PROFIL-file round trip, the rescale, IBORM and the
+            # output level all inside sosgpu_profile (its host half computes the no-gas profile in C++; the Python restatement
+            # profile_nogas costs 2-3 ms of a 7 ms call and stays as the checker of tests/test_profile.py)
+            try:
+                bins = ctx.make_profiles(1, tr, p["hr"], ta, ha, None, None, a_tronc=a_tronc, piz=piz, piztr=piztr, zout=zout,
+                                         absprofil=7)
+            except Exception as e:
+                raise SosProcError("SOS_PROFILE: %s" % e, ier=-1)
+            aik = np.ones(1)
+            tabs_flux = np.zeros(_abs.NLEVEL)
+        elif not use_gas:
+            h, xdel, ydel, zprof = profile_layer(tr, p["hr"], ta, float(p["zmin"]), float(p["zmax"]))
             ttot_vrai = h[-1]
             h, xdel, ydel, ib = rescale_profile(h, xdel, ydel, a_tronc, piz, piztr, os_nb)   # SOS.F:523-550
             bins = ctx.upload_bins(h[None], xdel[None], ydel[None], iborm=np.array([min(ib, iborm)], dtype=np.int32),
