@@ -684,7 +684,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         }
         if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
         nord = s + 1;
-        if (spec) bn.spec_i3[((size_t)b * S1 + s) * NTH + t] = i3;     // (the test below runs on partial sums: its result is not used)
+        // (The order loop is left by its regular exits also in this form: the test below then runs on partial sums and its
+        //  result is not used.  A `break` right here made the <4,2,ZO,SURF> variant -- 63 spilled VGPRs -- hand the replay
+        //  I3 terms that stopped the series early although its records were right; not understood, test
+        //  test_streamed_order_parallel_form_equals_per_bin_launch[1-25-80-True-True-0] is the witness.)
+        if (spec) bn.spec_i3[((size_t)b * S1 + s) * NTH + t] = i3;
         PH(6);
         const double a3 = fabs(i3);                                                                 // SOS_ARRET_FOURIER
         const bool pf = active && ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5)));
