@@ -5,6 +5,20 @@
  * the caller (the Python host allocates them with torch); `stream` is a hipStream_t passed as void*
  * (NULL = default stream).  Calls are asynchronous on `stream` unless stated.
  *
+ * Streams (the ordering rule).  No entry point synchronises the device, and none touches the null stream on its own:
+ *   - entry points taking `stream` queue ALL their device work on it and -- unless documented "synchronous" -- return
+ *     without waiting; their d_ inputs must have been produced on `stream` (or be complete) and must stay allocated
+ *     until the queued work has run;
+ *   - host-synchronous entry points without a stream argument (sosgpu_create, sosgpu_set_surface_matrices,
+ *     sosgpu_ctx_table, sosgpu_noyaux_fetch, sosgpu_os_flops) move their data on a private non-blocking stream of the
+ *     calling host thread and wait for that stream only; the last two first wait for the streams THIS context's work
+ *     was queued on.  What they wrote is complete on return, so work queued afterwards on any stream sees it;
+ *   - a context may be used from one host thread at a time; different contexts may be driven from different host
+ *     threads on different streams concurrently (run_sos.sos_proc_many), and no call waits for another thread's work;
+ *   - sosgpu_destroy waits for the streams the context's own work was queued on, nothing else.
+ * Device memory of contexts and of temporaries is recycled through a process-wide pool (hipFree would synchronise the
+ * device); sosgpu_trim() returns it.
+ *
  * Each entry point replaces one routine of the reference per-wavelength pipeline that
  * binding/run_sos.py reaches through sos.sos_proc (binding/run_sos.py:640, SOS_PROC.F:415):
  *
@@ -73,9 +87,13 @@ int  sosgpu_destroy(sosgpu_ctx *cx);
 /* Surface reflection matrices for imat_surf=1: REAL*4, reference FICSURF record order
  * d_rsurf[s][ab][(J-1)*N+(I-1)] = R_ab(I,J), s = 0..iborm_max (SOS_OS.F:916-925).  Device pointer; the call
  * packs them into the context as FP64 ground-reflection operators in matrix-core fragment order (weights, 2/mu and the
- * Lambertian part folded in) and synchronises the device -- the caller may release d_rsurf afterwards.  Call it after
- * sosgpu_create and before sosgpu_os_solve. */
+ * Lambertian part folded in).  Host-synchronous: d_rsurf must be complete when the call is made and may be released when it
+ * returns (see "Streams" above; no device-wide synchronisation).  Call it after sosgpu_create and before sosgpu_os_solve. */
 int  sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf);
+/* Stream-ordered form of the same: the packing is queued on `stream` and nothing is waited for (d_rsurf complete or being
+ * produced on `stream`; keep it allocated until the stream has passed this point).  Solves queued later on the same stream
+ * see the operators; solves on OTHER streams must be ordered after it by the caller (event / synchronise). */
+int  sosgpu_set_surface_matrices_async(sosgpu_ctx *cx, const float *d_rsurf, void *stream);
 
 /* Replaces SOS_NOYAUX (SOS_OS.F:1857-2158) for every Fourier order 0..iborm_max at once; must be called
  * once per context before sosgpu_os_solve.  Fills the context's packed source operators. */
@@ -95,8 +113,10 @@ int  sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out);
  *              0 = standard output (ZOUT = -1: TOA up, ground down).  May be NULL (= all 0).
  *  d_zz[nb]    interpolation weight ZZ (SOS_OS.F:1520); ignored when jout = 0.  May be NULL.
  * outputs
- *  d_rec[nb][iborm_max+1][3][W]  Fourier records; only orders 0..d_norders[b]-1 are written (the reference's FICOS file
- *                                of a bin holds one record per order run, SOS_OS.F:1571-1575)
+ *  d_rec[nb][iborm_max+1][3][W]  Fourier records; only orders 0..d_norders[b]-1 hold records on return (the reference's FICOS
+ *                                file of a bin holds one record per order run, SOS_OS.F:1571-1575): a buffer zero-filled by the
+ *                                caller is zero beyond them (the order-parallel launch form computes a few orders past the
+ *                                stop and clears their rows again)
  *  d_norders[nb]                 number of Fourier orders run (int32); -1 = malformed bin (NT < 1, NT >= lp, IBORM out of
  *                                range: the reference's IER = -1), nothing else is written for it
  *  d_iglast[nb][iborm_max+1]     last scattering order computed per Fourier order (int32)
@@ -238,8 +258,9 @@ int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
  * Outputs (device): d_prof[nb][3][lp] (H, XDEL, YDEL as sosgpu_os_solve takes them), d_nt[nb] (-1: the profile needs
  * more than CTE_OS_NT = 600 levels or lp is too small -- the reference's IER = -1), d_iborm[nb], d_zprof[nb][lp],
  * d_jout[nb] / d_zz[nb] (NULL when zout = -1), d_scal[nb][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT} (the layout
- * sosgpu_aggregate takes).  The no-gas profile of the wavelength is computed on the host and uploaded first: the call
- * synchronises `stream` once before launching.  IPROFIL = 2 (aerosol layer between two altitudes) is not implemented
+ * sosgpu_aggregate takes).  The no-gas profile of the wavelength is computed on the host and uploaded first on the calling
+ * thread's private stream; `stream` itself is not waited for (a second call on the same context first waits for the
+ * context's earlier work).  IPROFIL = 2 (aerosol layer between two altitudes) is not implemented
  * (the reference's branch reads an unassigned Hmol(0), its output is not reproducible). */
 int  sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, double ha, int absprofil,
                     int nblev, const double *d_altabs, const double *d_tabs,

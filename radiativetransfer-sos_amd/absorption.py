@@ -470,6 +470,29 @@ def absprofile_host(xk, ro, ik):
     return tau
 
 
+def band_bin_count(wa, nustep, root=None):
+    """Number of CKD bins of the spectral interval holding wavelength `wa` (microns): the product of the gases' numbers of
+    exponential terms NEXP (SOS_PROC.F:3381-3404), from the table files alone."""
+    nu = _F(1.0E+4) / wa
+    if nu > CKD_NUMAX or nu < CKD_NUMIN:
+        raise AbsorptionError("The simulation wavelength is not included in the spectral range of CKD data")
+    nb = 1
+    for k in range(1, NBABS + 1):
+        g = read_ckd_coeff(k, nu, nustep, root)
+        nb *= int(g["nexp"][int((g["numax"] - nu) / nustep)])
+    return nb
+
+
+def bin_costs(ik, xk, ro, tau_scat):
+    """Relative solver cost of every CKD bin of a band (dist.bin_cost) from its total gas absorption optical depth
+    sum_gas sum_layer k(gas, term, layer) RO(gas, layer) (the end value of SOS_ABSPROFILE.F:325-371 before the clamp)."""
+    from .dist import bin_cost
+    ik = np.asarray(ik)
+    col = np.einsum("gtl,gl->gt", xk, ro)                   # [gas][term] column optical depth
+    tg = col[np.arange(ik.shape[1])[None, :], ik - 1].sum(axis=1)
+    return bin_cost(tau_scat, tg)
+
+
 def bins(prep):
     """Bin list of the wavelength in the reference's solve order: (ik[nb][8] 1-based, aik[nb] normalised, sum before
     normalisation).  Raises like SOS_PROC.F:3414 when the weights do not sum to 1 within 1e-6."""

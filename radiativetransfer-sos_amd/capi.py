@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("SOSGPU_LIB") or os.path.join(HERE, "libsosgpu.so")
 # every symbol include/sosgpu.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
     "sosgpu_strerror", "sosgpu_last_hip_error", "sosgpu_device_count", "sosgpu_version",
-    "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_noyaux",
+    "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_set_surface_matrices_async", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
     "sosgpu_debug_phase_buffer", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
@@ -74,6 +74,8 @@ def lib():
         L.sosgpu_destroy.argtypes = [vp]
         L.sosgpu_set_surface_matrices.restype = i32
         L.sosgpu_set_surface_matrices.argtypes = [vp, vp]
+        L.sosgpu_set_surface_matrices_async.restype = i32
+        L.sosgpu_set_surface_matrices_async.argtypes = [vp, vp, vp]
         L.sosgpu_noyaux.restype = i32
         L.sosgpu_noyaux.argtypes = [vp, vp]
         L.sosgpu_noyaux_fetch.restype = i32

@@ -26,10 +26,12 @@ struct sosgpu_ctx {
     int device;
     SosDev d;
     std::vector<void *> allocs;
+    std::vector<size_t> alloc_cls;   // size class of each entry of allocs (mem_give)
     size_t bytes;
     hipEvent_t ev0, ev1;
     bool timed;
     hipStream_t last_stream;
+    std::vector<hipStream_t> used_streams;   // every stream a solve / table build of this context was queued on
     int nt_max_hint;
     double ind_surf;
     unsigned long long *phase;   // diagnostic phase-cycle buffer (sosgpu_debug_phase_buffer), else null
@@ -64,15 +66,126 @@ extern "C" int sosgpu_device_count(void)
     return n;
 }
 
+// Device memory of the per-wavelength tables and of the entry points' temporaries comes from a process-wide pool of released
+// blocks (size classes: 256 B steps up to 4 KiB, then eighths of the leading power of two; at most 4 GiB / 1024 blocks kept).
+// One sos_proc call = one context: without the pool every call pays ~10 hipMalloc + hipFree, and hipFree waits for the
+// whole device -- i.e. for the kernels of every other host thread.  A block is only returned after the work that used it has been
+// waited for (sosgpu_destroy: the context's streams; temporaries: their stream).  sosgpu_trim() empties the pool.
+namespace {
+struct PoolBlock { void *p; size_t n; int dev; };
+std::mutex g_mem_mutex;
+std::vector<PoolBlock> g_mem_free;
+size_t g_mem_bytes = 0;
+
+size_t mem_class(size_t n)
+{
+    if (n <= 4096) return (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
+    size_t p2 = 1;
+    while ((p2 << 1) <= n) p2 <<= 1;
+    const size_t step = p2 >> 3;
+    return (n + step - 1) / step * step;
+}
+
+void mem_trim()
+{
+    std::vector<PoolBlock> all;
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        all.swap(g_mem_free);
+        g_mem_bytes = 0;
+    }
+    for (const PoolBlock &b : all) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+}
+
+// *cls receives the size class (pass it back to mem_give); nullptr on failure
+void *mem_take(int dev, size_t bytes, size_t *cls)
+{
+    const size_t c = mem_class(bytes);
+    *cls = c;
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        for (size_t i = g_mem_free.size(); i-- > 0;)
+            if (g_mem_free[i].dev == dev && g_mem_free[i].n == c) {
+                void *p = g_mem_free[i].p;
+                g_mem_free.erase(g_mem_free.begin() + i);
+                g_mem_bytes -= c;
+                return p;
+            }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, c) != hipSuccess) {
+        (void)hipGetLastError();
+        sosgpu_trim();                             // the pools themselves may be what fills the device: release and retry once
+        (void)hipSetDevice(dev);
+        if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+    }
+    return p;
+}
+
+void mem_give(int dev, void *p, size_t cls)
+{
+    if (!p) return;
+    std::vector<PoolBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        g_mem_free.push_back({p, cls, dev});
+        g_mem_bytes += cls;
+        while (g_mem_free.size() > 1024 || g_mem_bytes > ((size_t)4 << 30)) {      // oldest first
+            g_mem_bytes -= g_mem_free.front().n;
+            drop.push_back(g_mem_free.front());
+            g_mem_free.erase(g_mem_free.begin());
+        }
+    }
+    for (const PoolBlock &b : drop) (void)hipFree(b.p);
+}
+
+// temporary of one entry point: taken from the pool, returned by the destructor (the entry point has waited for its stream)
+struct TmpBuf {
+    int dev; void *p; size_t cls;
+    TmpBuf(int device, size_t bytes) : dev(device), p(mem_take(device, bytes, &cls)) {}
+    ~TmpBuf() { mem_give(dev, p, cls); }
+    TmpBuf(const TmpBuf &) = delete;
+    TmpBuf &operator=(const TmpBuf &) = delete;
+};
+}   // namespace
+
 template <typename T>
 static int dev_alloc(sosgpu_ctx *cx, T **p, size_t count)
 {
-    void *q = nullptr;
-    HIPCHK(hipMalloc(&q, count * sizeof(T)));
+    size_t cls = 0;
+    void *q = mem_take(cx->device, count * sizeof(T), &cls);
+    if (!q) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
     cx->allocs.push_back(q);
+    cx->alloc_cls.push_back(cls);
     cx->bytes += count * sizeof(T);
     *p = static_cast<T *>(q);
     return 0;
+}
+
+// Ordering rule of the library (include/sosgpu.h, "Streams"): no entry point synchronises the DEVICE and none uses the
+// null stream.  Host-synchronous entry points (sosgpu_create, sosgpu_ctx_table, sosgpu_os_flops, ...) move their data on a
+// utility stream of the calling thread (non-blocking, created on first use, one per device) and wait for THAT stream only, so
+// a call never waits for -- or is overtaken by -- work other host threads have queued on their own streams.
+static hipStream_t util_stream(int device)
+{
+    static thread_local hipStream_t st[16] = {nullptr};
+    if (device < 0 || device >= 16) return nullptr;
+    if (!st[device] && hipStreamCreateWithFlags(&st[device], hipStreamNonBlocking) != hipSuccess) st[device] = nullptr;
+    return st[device];
+}
+
+static void note_stream(sosgpu_ctx *cx, hipStream_t st)
+{
+    cx->last_stream = st;
+    if (std::find(cx->used_streams.begin(), cx->used_streams.end(), st) == cx->used_streams.end()) cx->used_streams.push_back(st);
+}
+
+// waits for everything this context has queued (its solves may be in flight on several streams of the caller)
+static hipError_t sync_ctx_streams(sosgpu_ctx *cx)
+{
+    hipError_t e = hipSuccess;
+    for (hipStream_t st : cx->used_streams) { const hipError_t r = hipStreamSynchronize(st); if (e == hipSuccess) e = r; }
+    return e;
 }
 
 extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv, const double *mu, const double *ga,
@@ -164,9 +277,11 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     }
     double *p;
     int rc;
+    hipStream_t us = util_stream(device);
+    if (!us) { delete cx; return SOSGPU_E_HIP; }
 #define UP(dst, src, cnt)                                                                     \
     if ((rc = dev_alloc(cx, &p, (cnt)))) { sosgpu_destroy(cx); return rc; }                   \
-    if (hipMemcpy(p, (src), (cnt) * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {   \
+    if (hipMemcpyAsync(p, (src), (cnt) * sizeof(double), hipMemcpyHostToDevice, us) != hipSuccess) {   \
         sosgpu_destroy(cx); return SOSGPU_E_HIP; }                                            \
     dst = p;
     UP(d.mu, mu, (size_t)N)
@@ -177,7 +292,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     {
         int32_t *q = nullptr;
         if ((rc = dev_alloc(cx, &q, rowmap.size()))) { sosgpu_destroy(cx); return rc; }
-        if (hipMemcpy(q, rowmap.data(), rowmap.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMemcpyAsync(q, rowmap.data(), rowmap.size() * sizeof(int32_t), hipMemcpyHostToDevice, us) != hipSuccess) {
             sosgpu_destroy(cx); return SOSGPU_E_HIP; }
         d.rowmap = q;
         d.nwgt = nwgt;
@@ -191,12 +306,13 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
         sosgpu_destroy(cx);
         return rc;
     }
-    // (hipMemset returns before the fill has run, and the fills are ordered on the NULL stream only: sosgpu_noyaux writes these
-    //  tables on the caller's stream, which -- a non-blocking stream of a host thread, run_sos.sos_proc_many -- does not wait for
-    //  the null stream.  Without the synchronisation the fill could land on top of the packed molecular operator.)
-    if (hipMemset(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double)) != hipSuccess ||
-        hipMemset(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double)) != hipSuccess ||
-        hipStreamSynchronize(nullptr) != hipSuccess) {
+    // The uploads above (their host sources are locals of this call) and the two fills run on the calling thread's utility
+    // stream and are waited for here: when the call returns every table is in place, whatever stream sosgpu_noyaux and the
+    // solves are queued on afterwards.  (Round 2 filled on the null stream: a non-blocking caller stream does not wait for it,
+    // and a fill could land on top of the molecular operator sosgpu_noyaux had already packed.)
+    if (hipMemsetAsync(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double), us) != hipSuccess ||
+        hipMemsetAsync(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double), us) != hipSuccess ||
+        hipStreamSynchronize(us) != hipSuccess) {
         g_last_hip = (int)hipGetLastError();
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;
@@ -234,7 +350,12 @@ double *pool_take(int dev, size_t need, size_t *got)
     }
     double *p = nullptr;
     if (getenv("SOSGPU_DEBUG_POOL")) fprintf(stderr, "[sosgpu pool] hipMalloc %.1f MB\n", need * 8e-6);
-    if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) return nullptr;
+    if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        sosgpu_trim();                             // up to 8 GiB of kept scratch + 4 GiB of kept tables: release, retry once
+        (void)hipSetDevice(dev);
+        if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) return nullptr;
+    }
     *got = need;
     return p;
 }
@@ -267,6 +388,7 @@ extern "C" int sosgpu_trim(void)
         all.swap(g_pool);
     }
     for (const ScratchBuf &b : all) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    mem_trim();
     return SOSGPU_OK;
 }
 
@@ -275,12 +397,9 @@ extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
     if (!cx) return SOSGPU_OK;
     // teardown: nothing useful can be done with a failing free, errors are deliberately dropped
     (void)hipSetDevice(cx->device);
-    for (void *p : cx->allocs) (void)hipFree(p);
-    if (cx->scratch) {
-        if (cx->timed) (void)hipStreamSynchronize(cx->last_stream);     // its last solve may still be running
-        pool_give(cx->device, cx->scratch, cx->scratch_doubles);
-    }
-    if (cx->prof_ng) (void)hipFree(cx->prof_ng);
+    (void)sync_ctx_streams(cx);        // solves / table builds of this context may still be running, on any of its streams
+    for (size_t i = 0; i < cx->allocs.size(); i++) mem_give(cx->device, cx->allocs[i], cx->alloc_cls[i]);
+    if (cx->scratch) pool_give(cx->device, cx->scratch, cx->scratch_doubles);
     if (cx->ev0) (void)hipEventDestroy(cx->ev0);
     if (cx->ev1) (void)hipEventDestroy(cx->ev1);
     delete cx;
@@ -325,7 +444,7 @@ __global__ void k_pack_ground(SosDev cx, const float *__restrict__ r, double *__
     }
 }
 
-extern "C" int sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf)
+static int set_surface_matrices_impl(sosgpu_ctx *cx, const float *d_rsurf, hipStream_t st)
 {
     if (!cx) return SOSGPU_E_ARG;
     if (cx->d.imat_surf && !d_rsurf) return SOSGPU_E_ARG;
@@ -338,12 +457,31 @@ extern "C" int sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf)
         if (rc) return rc;
     }
     dim3 grid((unsigned)((std::max(per, (size_t)3 * cx->d.n) + 255) / 256), (unsigned)S1);
-    HIPCHK(hipDeviceSynchronize());          // d_rsurf may still be in the making on any stream of the caller
-    k_pack_ground<<<grid, 256>>>(cx->d, d_rsurf, cx->gnd_op, cx->gnd_dir);
+    k_pack_ground<<<grid, 256, 0, st>>>(cx->d, d_rsurf, cx->gnd_op, cx->gnd_dir);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());          // the caller may release or overwrite d_rsurf afterwards
+    note_stream(cx, st);
     cx->d.mp_gnd = cx->gnd_op;
     cx->d.rdir = cx->gnd_dir;
+    return SOSGPU_OK;
+}
+
+// stream-ordered form: the packing kernel is queued on `stream` (where d_rsurf was produced, or after it was complete) and
+// nothing is waited for; d_rsurf must stay allocated until that work has run
+extern "C" int sosgpu_set_surface_matrices_async(sosgpu_ctx *cx, const float *d_rsurf, void *stream)
+{
+    return set_surface_matrices_impl(cx, d_rsurf, (hipStream_t)stream);
+}
+
+// host-synchronous form (round 1's contract: the caller may release d_rsurf on return).  d_rsurf must be complete when the call
+// is made -- the packing runs on the calling thread's utility stream, which is all the call waits for.
+extern "C" int sosgpu_set_surface_matrices(sosgpu_ctx *cx, const float *d_rsurf)
+{
+    if (!cx) return SOSGPU_E_ARG;
+    hipStream_t us = util_stream(cx->device);
+    if (!us) return SOSGPU_E_HIP;
+    const int rc = set_surface_matrices_impl(cx, d_rsurf, us);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(us));
     return SOSGPU_OK;
 }
 
@@ -353,6 +491,7 @@ extern "C" int sosgpu_noyaux(sosgpu_ctx *cx, void *stream)
     HIPCHK(hipSetDevice(cx->device));
     launch_noyaux(cx->d, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    note_stream(cx, (hipStream_t)stream);
     return SOSGPU_OK;
 }
 
@@ -361,13 +500,15 @@ extern "C" int sosgpu_noyaux_fetch(sosgpu_ctx *cx, int is, double *out)
     if (!cx || !out || is < 0 || is > cx->d.smax) return SOSGPU_E_ARG;
     HIPCHK(hipSetDevice(cx->device));
     const size_t cnt = (size_t)6 * cx->d.w * cx->d.w + 3 * cx->d.w;
-    double *tmp = nullptr;
-    HIPCHK(hipMalloc((void **)&tmp, cnt * sizeof(double)));
-    HIPCHK(hipDeviceSynchronize());          // sosgpu_noyaux may still be running on a stream the null stream does not wait for
-    launch_noyaux_fetch(cx->d, is, tmp, nullptr);
-    hipError_t e = hipMemcpy(out, tmp, cnt * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
-    HIPCHK(e);
+    hipStream_t us = util_stream(cx->device);
+    if (!us) return SOSGPU_E_HIP;
+    TmpBuf tmp(cx->device, cnt * sizeof(double));
+    if (!tmp.p) return SOSGPU_E_HIP;
+    HIPCHK(sync_ctx_streams(cx));            // sosgpu_noyaux may still be running on the stream it was queued on
+    launch_noyaux_fetch(cx->d, is, (double *)tmp.p, us);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, tmp.p, cnt * sizeof(double), hipMemcpyDeviceToHost, us));
+    HIPCHK(hipStreamSynchronize(us));
     return SOSGPU_OK;
 }
 
@@ -437,7 +578,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         const size_t need = per_bin * regions + i3_doubles + (256 + (size_t)per_launch) / 2 + 1;
         if (need > cx->scratch_doubles) {
             if (cx->scratch) {
-                HIPCHK(hipDeviceSynchronize()); // a solve of this context may still be in flight on another stream
+                HIPCHK(sync_ctx_streams(cx));   // an earlier solve of this context may still be using it, on any of its streams
                 pool_give(cx->device, cx->scratch, cx->scratch_doubles);
             }
             cx->scratch = nullptr;
@@ -514,7 +655,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
     }
     HIPCHK(hipEventRecord(cx->ev1, st));
     cx->timed = true;
-    cx->last_stream = st;
+    note_stream(cx, st);
     return SOSGPU_OK;
 }
 
@@ -544,7 +685,10 @@ extern "C" int sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table
         tab[i] = d;
     }
     HIPCHK(hipSetDevice(ctxs[0]->device));
-    HIPCHK(hipMemcpy(d_table, tab.data(), (size_t)nctx * sizeof(SosDev), hipMemcpyHostToDevice));
+    hipStream_t us = util_stream(ctxs[0]->device);
+    if (!us) return SOSGPU_E_HIP;
+    HIPCHK(hipMemcpyAsync(d_table, tab.data(), (size_t)nctx * sizeof(SosDev), hipMemcpyHostToDevice, us));
+    HIPCHK(hipStreamSynchronize(us));
     return SOSGPU_OK;
 }
 
@@ -574,9 +718,13 @@ extern "C" int sosgpu_os_flops(sosgpu_ctx *cx, int nb, const int32_t *d_nt, cons
     HIPCHK(hipSetDevice(cx->device));
     const int S1 = cx->d.smax + 1;
     std::vector<int32_t> nt(nb), no(nb), ig((size_t)nb * S1);
-    HIPCHK(hipMemcpy(nt.data(), d_nt, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(no.data(), d_norders, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ig.data(), d_iglast, (size_t)nb * S1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    hipStream_t us = util_stream(cx->device);
+    if (!us) return SOSGPU_E_HIP;
+    HIPCHK(sync_ctx_streams(cx));              // the solve whose counts are read
+    HIPCHK(hipMemcpyAsync(nt.data(), d_nt, nb * sizeof(int32_t), hipMemcpyDeviceToHost, us));
+    HIPCHK(hipMemcpyAsync(no.data(), d_norders, nb * sizeof(int32_t), hipMemcpyDeviceToHost, us));
+    HIPCHK(hipMemcpyAsync(ig.data(), d_iglast, (size_t)nb * S1 * sizeof(int32_t), hipMemcpyDeviceToHost, us));
+    HIPCHK(hipStreamSynchronize(us));
     const double r6 = 6.0 * cx->d.n, r3 = 3.0 * cx->d.n, k3 = 3.0 * cx->d.nwgt;
     double tot = 0., exe = 0.;
     for (int b = 0; b < nb; b++) {
@@ -622,15 +770,12 @@ extern "C" int sosgpu_aggregate(sosgpu_ctx *cx, int nb, int nseg, const int32_t 
     const int max_chunks = 4096;
     const int nb_single = (nseg == 1) ? nb : 0;      // one band: big batches use the chunked reduction
     if (nb_single > 128 && !cx->agg_partial) {
-        void *q = nullptr;
-        HIPCHK(hipMalloc(&q, (size_t)nel * max_chunks * sizeof(double)));
-        cx->agg_partial = (double *)q;
-        cx->allocs.push_back(q);
-        cx->bytes += (size_t)nel * max_chunks * sizeof(double);
+        if (int rc = dev_alloc(cx, &cx->agg_partial, (size_t)nel * max_chunks)) return rc;
     }
     launch_aggregate(cx->d, nseg, d_seg, d_aik, d_rec, d_norders, d_flux, d_scal, d_tdifmug, d_out_rec, d_out_scal, st,
                      nb_single, cx->agg_partial, max_chunks);
     HIPCHK(hipGetLastError());
+    note_stream(cx, st);
     return SOSGPU_OK;
 }
 
@@ -651,9 +796,8 @@ struct Rccl {
 };
 }  // namespace
 static Rccl g_rccl;
-static int rccl_load()
+static int rccl_load_once()
 {
-    if (g_rccl.h) return 0;
     void *h = nullptr;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -671,6 +815,13 @@ static int rccl_load()
         return SOSGPU_E_RCCL;
     g_rccl.h = h;
     return 0;
+}
+static int rccl_load()
+{
+    static std::once_flag once;            // host threads may reach the first RCCL call together
+    static int rc = SOSGPU_E_RCCL;
+    std::call_once(once, [] { rc = rccl_load_once(); });
+    return rc;
 }
 
 extern "C" int sosgpu_comm_unique_id(char id[SOSGPU_UNIQUE_ID_BYTES])
@@ -738,15 +889,15 @@ extern "C" int sosgpu_reduce(sosgpu_ctx *cx, void *comm, int nseg, double *d_buf
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t nel = (size_t)(cx->d.smax + 1) * 3 * cx->d.w, row = nel + SOSGPU_SCAL_BASE + cx->d.n;
-    double *mx = nullptr;
-    HIPCHK(hipMalloc((void **)&mx, (size_t)2 * nseg * sizeof(double)));
+    TmpBuf mxb(cx->device, (size_t)2 * nseg * sizeof(double));
+    if (!mxb.p) return SOSGPU_E_HIP;
+    double *mx = (double *)mxb.p;
     k_reduce_save<<<(2 * nseg + 63) / 64, 64, 0, st>>>(nseg, row, nel, d_buf, mx, 0);
     const int ncclDouble = 8, ncclSum = 0, ncclMax = 2;    // nccl.h enumerators (ncclFloat64 = 8)
     int bad = g_rccl.AllReduce(d_buf, d_buf, row * nseg, ncclDouble, ncclSum, comm, st);
     bad |= g_rccl.AllReduce(mx, mx, (size_t)2 * nseg, ncclDouble, ncclMax, comm, st);
     k_reduce_save<<<(2 * nseg + 63) / 64, 64, 0, st>>>(nseg, row, nel, d_buf, mx, 1);
     hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(mx);
     if (bad) return SOSGPU_E_RCCL;
     HIPCHK(e);
     return SOSGPU_OK;
@@ -854,18 +1005,19 @@ extern "C" int sosgpu_glitter(int device, int n, const double *mu, const double 
     std::vector<double> fcoef((size_t)4 * (os_ns + 1));
     int rc = sosgpu_mat_fresnel_host(n, mu, chr, ind, os_ns, fcoef.data());
     if (rc) return rc;
-    double *d_buf = nullptr;
     const size_t cnt = (size_t)n + fcoef.size();
-    HIPCHK(hipMalloc((void **)&d_buf, cnt * sizeof(double)));
+    TmpBuf tb(device, cnt * sizeof(double));
+    if (!tb.p) return SOSGPU_E_HIP;
+    double *d_buf = (double *)tb.p;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemcpy(d_buf, mu, n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_buf + n, fcoef.data(), fcoef.size() * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(d_buf, mu, n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_buf + n, fcoef.data(), fcoef.size() * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         launch_glitter(n, d_buf, sigma2_of_wind(wind), os_nb, os_ns, os_nm, d_buf + n, d_il, d_e, d_rsurf, st);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_buf);
+    else (void)hipStreamSynchronize(st);
     HIPCHK(e);
     return SOSGPU_OK;
 }
@@ -915,8 +1067,9 @@ extern "C" int sosgpu_land_surface(int device, const sosgpu_land *land, int n, c
     // one allocation: mu | fcoef | e_nn [N^2][os_nb+1] | e [npairs][os_nm+1] | il_nn, il, err (int32) | tmp matrices (float)
     const size_t nd = (size_t)n + fcoef.size() + nn * (os_nb + 1) + npairs * (os_nm + 1);
     const size_t ni = nn + npairs + 2;
-    char *buf = nullptr;
-    HIPCHK(hipMalloc((void **)&buf, nd * 8 + ni * 4 + cnt * 4 + 64));
+    TmpBuf tb(device, nd * 8 + ni * 4 + cnt * 4 + 64);
+    if (!tb.p) return SOSGPU_E_HIP;
+    char *buf = (char *)tb.p;
     double *d_mu = (double *)buf, *d_fc = d_mu + n, *d_enn = d_fc + fcoef.size(), *d_e = d_enn + nn * (os_nb + 1);
     int32_t *d_ilnn = (int32_t *)(d_e + npairs * (os_nm + 1)), *d_il = d_ilnn + nn, *d_err = d_il + npairs;
     float *d_tmp = (float *)(d_err + 2);
@@ -931,7 +1084,7 @@ extern "C" int sosgpu_land_surface(int device, const sosgpu_land *land, int n, c
     }
     if (e == hipSuccess) e = hipMemcpyAsync(err, d_err, sizeof err, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(buf);
+    else (void)hipStreamSynchronize(st);
     HIPCHK(e);
     if (ier_out) *ier_out = err[0] ? -1 : 0;
     return SOSGPU_OK;
@@ -1020,9 +1173,14 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     const int nt_ng = profile_nogas_host(tr, hr, ta, ha, &ng[0], &ng[NG], &ng[2 * NG], &ng[3 * NG]);
     if (nt_ng < 0) return SOSGPU_E_UNSUPPORTED;        // more than CTE_OS_NT levels (IER = -1 in the reference)
     if (lp <= nt_ng) return SOSGPU_E_ARG;
-    if (!cx->prof_ng) HIPCHK(hipMalloc((void **)&cx->prof_ng, (size_t)4 * NG * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(cx->prof_ng, ng.data(), (size_t)4 * NG * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));                 // ng is a stack-lifetime host buffer
+    // the no-gas profile goes up on the calling thread's utility stream (waited for: `ng` is a local) -- `stream` itself is
+    // never waited for, so profiles, solve and aggregate of a wavelength queue up behind one another without a host stall
+    hipStream_t us = util_stream(cx->device);
+    if (!us) return SOSGPU_E_HIP;
+    if (!cx->prof_ng) { if (int rc = dev_alloc(cx, &cx->prof_ng, (size_t)4 * NG)) return rc; }
+    else HIPCHK(sync_ctx_streams(cx));                // an earlier sosgpu_profile of this context may still be reading it
+    HIPCHK(hipMemcpyAsync(cx->prof_ng, ng.data(), (size_t)4 * NG * sizeof(double), hipMemcpyHostToDevice, us));
+    HIPCHK(hipStreamSynchronize(us));
     ProfileArgs a;
     a.nb = nb; a.lp = lp; a.nblev = nblev; a.absprofil = d_tabs ? absprofil : 7; a.smax = cx->d.smax; a.nt_ng = nt_ng;
     a.tr = tr; a.hr = hr; a.ta = ta; a.ha = ha; a.a_tronc = a_tronc; a.piz = piz; a.piztr = piztr; a.zout = zout;
@@ -1031,6 +1189,7 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     a.prof = d_prof; a.zprof = d_zprof; a.zz = d_zz; a.scal = d_scal; a.nt = d_nt; a.iborm = d_iborm; a.jout = d_jout;
     launch_profile(a, st);
     HIPCHK(hipGetLastError());
+    note_stream(cx, st);
     return SOSGPU_OK;
 }
 
@@ -1068,8 +1227,9 @@ extern "C" int sosgpu_mie(int device, int nbmu, const double *xmu, double rn, do
     }
     if (2 * amax + 24 > 10000) return SOSGPU_E_UNSUPPORTED;                      // CTE_MIE_DIM, SOS.h:117
     const size_t nscr = n_lds < nalpha ? mie_scratch_doubles(amax) : 0;
-    char *buf = nullptr;
-    HIPCHK(hipMalloc((void **)&buf, (size_t)(W + nalpha + nscr) * sizeof(double) + 64));
+    TmpBuf tb(device, (size_t)(W + nalpha + nscr) * sizeof(double) + 64);
+    if (!tb.p) return SOSGPU_E_HIP;
+    char *buf = (char *)tb.p;
     double *d_xmu = (double *)buf, *d_al = d_xmu + W, *d_scr = d_al + nalpha;
     int32_t *d_err = (int32_t *)(d_scr + nscr);
     int32_t err = 0;
@@ -1083,8 +1243,7 @@ extern "C" int sosgpu_mie(int device, int nbmu, const double *xmu, double rn, do
     }
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(&err, d_err, sizeof err, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    else (void)hipDeviceSynchronize();
-    (void)hipFree(buf);
+    else (void)hipStreamSynchronize(st);
     if (rc == -3) return SOSGPU_E_UNSUPPORTED;
     if (rc == -2) { g_last_hip = (int)hipGetLastError(); return SOSGPU_E_HIP; }
     HIPCHK(e);

@@ -21,6 +21,7 @@
 //    tail, the Fourier accumulation and the Fourier stop are per-thread register state.
 // HBM traffic per bin: 3(NT+1) doubles in, (F*3*(2N+1) + small) doubles out; everything else is on chip
 // or L2/MALL-resident operator reads shared by all bins.
+#include <atomic>
 #include <cstdlib>
 #include "sos_dev.h"
 #include "kernels.h"
@@ -447,12 +448,13 @@ static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipSt
 #endif
     // the dynamic-LDS limit of a kernel is set once per device and size (the call costs tens of microseconds: with few bins per
     // wavelength the host launch path is what bounds a hyperspectral loop, scripts/spectrum_bench.py)
-    static size_t configured[16] = {0};
+    // (atomics: host threads of run_sos.sos_proc_many launch concurrently; a lost update only repeats the call)
+    static std::atomic<size_t> configured[16];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[dev] < lds)) {
+    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[dev].load(std::memory_order_acquire) < lds)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess && dev >= 0 && dev < 16) configured[dev] = lds;
+        if (e == hipSuccess && dev >= 0 && dev < 16) configured[dev].store(lds, std::memory_order_release);
     }
     if (e == hipSuccess) {
         kern<<<bn.nb, 64 * NW, lds, st>>>(cx, bn);

@@ -28,6 +28,7 @@
 // (SosBins::spec_k); a persistent launch taking (order, bin) tasks from per-XCD queues (PERSIST, opt-in); order-synchronous
 // launches (SosBins::s_begin / s_end, opt-in).  All of them run the same task body, run_task.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "sos_dev.h"
 #include "kernels.h"
@@ -829,6 +830,11 @@ __global__ __launch_bounds__(64 * NW) void k_sos_stream_replay(const SosDev cx, 
     }
     if (finished) {
         for (int i = t + nord; i < S1; i += NTH) bn.iglast[(size_t)b * S1 + i] = 0;
+        // the order tasks of this round past the stop have stored their records: sosgpu.h promises that only orders
+        // 0 .. norders-1 are written (a zero-filled d_rec stays zero beyond them), so those rows are cleared again
+        const int W3 = 3 * cx.w, s_hi = min(s1, iborm + 1);
+        double *recb = bn.rec + (size_t)b * S1 * W3;
+        for (int i = nord * W3 + t; i < s_hi * W3; i += NTH) recb[i] = 0.;
         if (t == 0) { bn.norders[b] = nord; state[0] = 1.; }
     } else {
         state[8 + 2 * t] = i4; state[8 + 2 * t + 1] = i5;
@@ -873,21 +879,22 @@ static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_
     const size_t lds = stream_lds_bytes(NW, RTWH);
     // the dynamic-LDS limit of a kernel is set once per device and size (the call costs tens of microseconds: with few bins per
     // wavelength the host launch path is what bounds a hyperspectral loop, scripts/spectrum_bench.py)
-    static size_t configured[2][16] = {{0}, {0}};
-    static int cus[16] = {0};
+    // (atomics: host threads of run_sos.sos_proc_many launch concurrently; a lost update only repeats the call)
+    static std::atomic<size_t> configured[2][16];
+    static std::atomic<int> cus[16];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[persist][dev] < lds)) {
+    if (e == hipSuccess && (dev < 0 || dev >= 16 || configured[persist][dev].load(std::memory_order_acquire) < lds)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess && dev >= 0 && dev < 16) configured[persist][dev] = lds;
+        if (e == hipSuccess && dev >= 0 && dev < 16) configured[persist][dev].store(lds, std::memory_order_release);
     }
     int grid = bn.spec_k > 0 ? bn.nb * bn.spec_k : bn.nb;
     if (e == hipSuccess && persist) {
         // as many workgroups as the chip hosts at once (two per CU for the 4-wave forms); fewer resident ones only cost speed
-        int ncu = (dev >= 0 && dev < 16) ? cus[dev] : 0;
+        int ncu = (dev >= 0 && dev < 16) ? cus[dev].load(std::memory_order_relaxed) : 0;
         if (!ncu) {
             e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e == hipSuccess && dev >= 0 && dev < 16) cus[dev] = ncu;
+            if (e == hipSuccess && dev >= 0 && dev < 16) cus[dev].store(ncu, std::memory_order_relaxed);
         }
         grid = std::min(bn.nb, ncu * (NW == 4 ? 2 : 1));
     }

@@ -21,6 +21,39 @@ def shard_range(nb, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def bin_cost(tau_scat, tau_abs):
+    """Relative cost of one CKD bin on the solver, from what the host knows before any profile exists: the scattering optical
+    depth of the wavelength (Rayleigh + aerosol) and the bin's total gas absorption optical depth.  Cost = levels x scattering
+    steps: SOS_PROFILE lays a level every CTE_TCOUCHE = 0.005 of total optical depth between CTE_OS_NT_MIN = 100 and CTE_OS_NT
+    = 600 levels, gas absorption counted up to CTE_THRESHOLD_TAUABS = 1.5 (SOS_PROFIL.F:349-361, 509-560; SOS.h:202-229,301);
+    the number of scattering orders falls as absorption removes the multiply scattered light (fitted on the realistic mix:
+    tests/test_dist_cpu.py checks the balance it gives against the true NT x orders of the oracle)."""
+    ts = np.asarray(tau_scat, dtype=np.float64)
+    tg = np.asarray(tau_abs, dtype=np.float64)
+    # levels: 1.12 x (tau_scat + tau_gas) / 0.005 (the gas-aware placement adds ~12 % to the plain count), gas capped at 1.5
+    # in a weak bin; a strong bin (tau_gas > 1.5) gets the levels of about one unit of gas; never below ~117
+    nt = np.clip(1.12 * (ts + np.where(tg > 1.5, 1.0, tg)) / 0.005, 117.0, 600.0)
+    steps = 1.0 / (1.0 + 0.12 * np.power(np.minimum(tg, 50.0), 0.7))
+    return nt * steps
+
+
+def balanced_shards(costs, world):
+    """Deal the items (CKD bins of a band, or wavelengths of a spectrum) to `world` ranks so that the summed cost per rank
+    is even: longest-processing-time-first (items by decreasing cost, each to the least loaded rank; ties to the lower rank,
+    so every rank computes the same partition).  Returns a list of `world` ascending index arrays -- within a rank the items
+    keep their original order (the order SOS_PROC.F:3459-3466 enumerates the bins in), some may be empty.  The CKD bins of a
+    band come strongest absorber first per gas, with NT 117...426 and 25...50 Fourier orders across a band: contiguous slices
+    (shard_range) are off by 10-30 % there."""
+    costs = np.asarray(costs, dtype=np.float64)
+    load = np.zeros(world)
+    owner = np.zeros(len(costs), dtype=np.int64)
+    for i in np.argsort(-costs, kind="stable"):
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += costs[i]
+    return [np.nonzero(owner == r)[0] for r in range(world)]
+
+
 def pack_partial(rec, scal):
     """rec [nseg][S][3][W], scal [nseg][10+N] -> one flat fp64 buffer per segment [nseg][S*3*W + 10 + N]."""
     nseg = rec.shape[0]

@@ -468,36 +468,6 @@ def profile_layer(tr, hr, ta, zmin, zmax):
     return _round_sig(h, 8), _round_sig(pcaer, 8), _round_sig(pcmol, 8), np.round(zprof, 5)
 
 
-def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, land=None):
-    """SOS_TRPHI_OPTION (SOS_TRPHI.F:431-615): run the azimuth recomposition on the GPU for the azimuth list of
-    the view mode and pack the fourteen (361,81) tables plus PHI_FIN(361), THETA_FIN(81)."""
-    n = ctx.n
-    teta = np.degrees(np.arccos(ctx.mu))
-    phi_fin = np.zeros(361)
-    theta_fin = np.zeros(81)
-    tabs = {k: np.zeros((361, 81)) for k in ("sca", "i", "q", "u", "ang", "rate", "lpol")}
-    tabs_dn = {k: np.zeros((361, 81)) for k in tabs}
-    if itrphi == 1:
-        phis = [math.pi + phios * math.pi / 180.0, phios * math.pi / 180.0]
-        rows = [0, 1]
-        phi_fin[0] = phios            # set to PHIOS+180 then overwritten by PHIOS (SOS_TRPHI.F:445,504)
-    elif itrphi == 2:
-        iphis = list(range(0, 361, int(pas_phi)))
-        phis = [math.pi * ip / 180.0 for ip in iphis]
-        rows = list(range(len(iphis)))
-        phi_fin[:len(iphis)] = iphis
-    else:
-        raise SosProcError("-SOS.View must be 1 or 2")
-    out = ctx.trphi(rec, nf, tau, tauout, phis, igli=igli, wind=wind, land=land).cpu().numpy()
-    theta_fin[:n] = teta
-    names = ["i", "q", "u", "sca", "ang", "rate", "lpol"]       # order of sosgpu_trphi's 7 output rows
-    for k, row in enumerate(rows):
-        for qi, nm in enumerate(names):
-            tabs[nm][row, :n] = out[k, qi, n + 1:]               # up-going jj = 1..N
-            tabs_dn[nm][row, :n] = out[k, qi, :n][::-1]          # down-going jj = -1..-N
-    return phi_fin, theta_fin, tabs, tabs_dn
-
-
 def read_surface_file(path, n, os_nb):
     """A surface reflection-matrix file in the reference's format (what SOS_SURFACE writes and SOS_OS reads, SOS_OS.F:916-925):
     one sequential unformatted record per Fourier order IS = 0..OS_NB holding the nine REAL*4 matrices P11 P12 P13 P21 ...
@@ -748,19 +718,62 @@ def _surface_cached(key, make, device):
     return r
 
 
-def sos_proc(aer_phase=None, device=0, **kw):
-    """Drop-in for `sos.sos_proc(**kwargs)` (f2py of SOS_PROC, SOS_PROC.F:415) on the MI355X hot path.
-    Returns the reference's 23-tuple (names in OUTPUT_NAMES).
+class _Plan:
+    """One wavelength between its host preparation (_prepare) and its outputs (_finish): the parameters, what the host
+    derived from them, the device context and the bins of its band."""
 
-    aer_phase (extension, not a reference keyword): dict(alpha, beta, gamma, zeta [OS_NB+1 each], piz, piztr,
-    a_tronc) -- the content of the reference's Aerosols.txt when `-AER.AOTref` > 0 (the Mie/size-distribution
-    step that produces it is outside this round's scope)."""
+
+def _trphi_azimuths(itrphi, phios, pas_phi):
+    """Azimuth list (radians), table rows and PHI_FIN of the view mode (SOS_TRPHI.F:431-615)."""
+    phi_fin = np.zeros(361)
+    if itrphi == 1:
+        phis = [math.pi + phios * math.pi / 180.0, phios * math.pi / 180.0]
+        rows = [0, 1]
+        phi_fin[0] = phios            # set to PHIOS+180 then overwritten by PHIOS (SOS_TRPHI.F:445,504)
+    elif itrphi == 2:
+        iphis = list(range(0, 361, int(pas_phi)))
+        phis = [math.pi * ip / 180.0 for ip in iphis]
+        rows = list(range(len(iphis)))
+        phi_fin[:len(iphis)] = iphis
+    else:
+        raise SosProcError("-SOS.View must be 1 or 2")
+    return phis, rows, phi_fin
+
+
+def _trphi_pack(n, mu, out, rows, phi_fin):
+    """sosgpu_trphi's [nphi][7][W] (host array) -> PHI_FIN, THETA_FIN and the fourteen (361,81) tables."""
+    theta_fin = np.zeros(81)
+    theta_fin[:n] = np.degrees(np.arccos(mu))
+    names = ["i", "q", "u", "sca", "ang", "rate", "lpol"]       # order of sosgpu_trphi's 7 output rows
+    tabs = {k: np.zeros((361, 81)) for k in names}
+    tabs_dn = {k: np.zeros((361, 81)) for k in names}
+    nr = len(rows)
+    for qi, nm in enumerate(names):
+        tabs[nm][rows, :n] = out[:nr, qi, n + 1:]               # up-going jj = 1..N
+        tabs_dn[nm][rows, :n] = out[:nr, qi, :n][:, ::-1]       # down-going jj = -1..-N
+    return phi_fin, theta_fin, tabs, tabs_dn
+
+
+def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, land=None):
+    """SOS_TRPHI_OPTION (SOS_TRPHI.F:431-615): run the azimuth recomposition on the GPU for the azimuth list of
+    the view mode and pack the fourteen (361,81) tables plus PHI_FIN(361), THETA_FIN(81)."""
+    phis, rows, phi_fin = _trphi_azimuths(itrphi, phios, pas_phi)
+    out = ctx.trphi(rec, nf, tau, tauout, phis, igli=igli, wind=wind, land=land).cpu().numpy()
+    return _trphi_pack(ctx.n, ctx.mu, out, rows, phi_fin)
+
+
+def _prepare(kw, aer_phase=None, device=0, shard_bins=True):
+    """Everything of one SOS_PROC call up to the CKD bin loop (SOS_PROC.F:1310-3458): parameter checks, SOS_ANGLES,
+    SOS_AEROSOLS, SOS_SURFACE, SOS_PREPA_ABSPROFILE, SOS_PREPA_OS, and the profiles of every bin of the band on the device
+    (SOS_ABSPROFILE + SOS_PROFILE + the rescale of SOS).  Returns a _Plan whose `ctx` the caller closes.
+    shard_bins: with torch.distributed initialised, keep only this rank's slice of the band's bins (sos_proc); False: the
+    whole band stays on this rank (sos_spectrum distributes wavelengths, not bins)."""
     missing = [k for k in SOS_PROC_KWARGS if k not in kw]
     if missing:
         raise TypeError("sos_proc() missing keyword arguments: %s" % ", ".join(missing))
     p = dict(kw)
     validate_parameters(p)
-    from .solver import SosContext, SosBinError
+    from .solver import SosContext
     from . import surface as _surface
     from . import absorption as _abs
     import torch
@@ -858,6 +871,7 @@ def sos_proc(aer_phase=None, device=0, **kw):
 
     # --- gas absorption: SOS_PREPA_ABSPROFILE + the weights of the CKD bins (SOS_PROC.F:3359-3416)
     use_gas = absprofil != 7
+    prep = None
     if iprofil == 2 and use_gas:                                                   # SOS_PROC.F:2352
         raise SosProcError("-AP.AerProfile.Type 2 requires -AP.AbsProfile.Type 7 (no gas absorption)")
     if use_gas:
@@ -922,9 +936,19 @@ def sos_proc(aer_phase=None, device=0, **kw):
     ctx = SosContext(mu, ga, n0, alpha, beta, gamma, zeta, iborm_max=iborm, ro=p["rho"], imat_surf=imat,
                      ifresnel=ifresnel, ind_surf=p["surf_ind"] if isurf in (1, 2) or isurf >= 4 else 1.34, ron=MDF_DEFAULT,
                      ipolar=int(p["ipolar"]), igmax=igmax, rsurf=rsurf, device=device)
+    pl = _Plan()
+    pl.p, pl.ctx, pl.device = p, ctx, device
+    pl.n, pl.mu, pl.ga, pl.n0, pl.ind_ang = n, mu, ga, n0, ind_ang
+    pl.nb_lum, pl.nb_mie, pl.os_nb, pl.os_ns, pl.os_nm = nb_lum, nb_mie, os_nb, os_ns, os_nm
+    pl.use_model, pl.aer_phase, pl.coef_tronca_out, pl.a_tronc = use_model, aer_phase, coef_tronca_out, a_tronc
+    pl.tr, pl.ta, pl.ha, pl.use_gas, pl.prep = tr, ta, ha, use_gas, prep
+    pl.itrphi, pl.igli, pl.land = itrphi, igli, land
+    pl.tdifmug = None
+    pl.want_trans = str(p["fictrans"]).strip() != "NO_OUTPUT"
     try:
-        # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device, one fused solve, one aggregate
+        # --- the CKD bin loop (SOS_PROC.F:3459-3594): profiles of every bin on the device
         band_sharded = False                          # True: every rank holds a slice of the band and the partials are all-reduced
+        tabs_flux = None                              # TAUABS of the band's last bin (Flux file): host array or [.][nlev] device tensor
         if not use_gas and iprofil == 1:
             # the single no-gas profile of the wavelength: SOS_PROFILE, the PROFIL-file round trip, the rescale, IBORM and the
             # output level all inside sosgpu_profile (its host half computes the no-gas profile in C++; the Python restatement
@@ -935,7 +959,6 @@ def sos_proc(aer_phase=None, device=0, **kw):
             except Exception as e:
                 raise SosProcError("SOS_PROFILE: %s" % e, ier=-1)
             aik = np.ones(1)
-            tabs_flux = np.zeros(_abs.NLEVEL)
         elif not use_gas:
             h, xdel, ydel, zprof = profile_layer(tr, p["hr"], ta, float(p["zmin"]), float(p["zmax"]))
             ttot_vrai = h[-1]
@@ -950,19 +973,18 @@ def sos_proc(aer_phase=None, device=0, **kw):
                 tauout = (1 - zzv) * h[j - 1] + zzv * h[j]                           # SOS.F:572-581
             bins["scal"] = np.array([[0.0, h[-1], ttot_vrai, tauout]])
             aik = np.ones(1)
-            tabs_flux = np.zeros(_abs.NLEVEL)
         else:
-            # Several GPUs (torch.distributed initialised, one process per GPU): the bins of the band are sharded
-            # contiguously over the ranks (dist.shard_range); solve_band's one all-reduce joins them and every rank returns
-            # the same 23 outputs.  A rank may hold no bin at all.  (-SOS.AbsModeCKD 2 has a single bin: not sharded.)
-            rank, world = _dist_rank_world()
-            lo, hi = (0, len(aik)) if (world == 1 or mode_ckd == 2) else _shard_range(len(aik), rank, world)
-            sharded = (hi - lo) != len(aik)
+            # Several GPUs (torch.distributed initialised, one process per GPU): the bins of the band are dealt to the ranks
+            # by cost (dist.balanced_shards); solve_band's one all-reduce joins them and every rank returns the same 23
+            # outputs.  A rank may hold no bin at all.  (-SOS.AbsModeCKD 2 has a single bin: not sharded.)
+            rank, world = _dist_rank_world() if shard_bins else (0, 1)
             band_sharded = world > 1 and mode_ckd != 2
             tabs_last = None
-            if sharded:
+            if band_sharded:
+                from . import dist as _dist
                 tabs_last = ctx.absorption_profiles(ik[-1:], xk, ro_lay)             # TAUABS of the band's last bin (Flux file)
-                ik, aik = ik[lo:hi], aik[lo:hi]
+                mine = _dist.balanced_shards(_abs.bin_costs(ik, xk, ro_lay, tr + ta), world)[rank]
+                ik, aik = ik[mine], aik[mine]
             tabs = ctx.absorption_profiles(ik, xk, ro_lay) if len(aik) else None     # SOS_ABSPROFILE of every bin of this rank
             if mode_ckd == 2:
                 # one profile from the band-mean transmission of every level (SOS_PROC.F:3609-3676)
@@ -980,63 +1002,95 @@ def sos_proc(aer_phase=None, device=0, **kw):
                     bins = dict(nb=0, scal=None)
             except Exception as e:
                 raise SosProcError("SOS_PROFILE: %s" % e, ier=-1)
-            tl = tabs_last if sharded else tabs
-            tabs_flux = (tl[-1].cpu().numpy() if hasattr(tl, "cpu") else np.asarray(tl)[-1])   # TAUABS of the last bin
-        tdifmug = None
-        want_trans = str(p["fictrans"]).strip() != "NO_OUTPUT"
-        if want_trans and bins["nb"]:                                                # SOS.F:600-635
-            tdifmus_b, tdifmug = ctx.diffuse_transmissions(bins)
+            tabs_flux = tabs_last if band_sharded else tabs
+        if pl.want_trans and bins["nb"]:                                             # SOS.F:600-635
+            tdifmus_b, pl.tdifmug = ctx.diffuse_transmissions(bins)
             sc = bins["scal"] if hasattr(bins["scal"], "clone") else torch.from_numpy(np.asarray(bins["scal"])).to(ctx.device)
             sc = sc.clone()
             sc[:, 0] = tdifmus_b
             bins["scal"] = sc
-        try:
-            rec, fin = ctx.solve_band(bins, aik, tdifmug=tdifmug, reduce=band_sharded)
-        except SosBinError as e:
-            raise SosProcError(str(e), ier=-1)
-        nf = int(fin["n_orders"][0])
-        tau_agg, tauout_agg = float(fin["ttot_tronc"][0]), float(fin["tauout"][0])
-        ttot_vrai_agg = float(fin["ttot_vrai"][0])
-        phi_fin, theta_fin, up, dn = trphi_tables(ctx, rec[0], nf, tau_agg, tauout_agg, itrphi, p["phios"], p["pas_phi"],
-                                                  igli, p["wind"] if igli else 0.0, land=land)
-        emoins, eplus = float(fin["emoins"][0]), float(fin["eplus"][0])
-        resbin = str(p["ficsos_res_bin"]).strip()
-        resroot = str(p["resroot"]).strip() if _dist_rank_world()[0] == 0 else ""      # files: rank 0 only
-        if resroot:                                   # SOS_PROC.F:1342-1500: results under RESROOT/SOS
-            os.makedirs(os.path.join(resroot, "SOS"), exist_ok=True)
-            # the two angle files SOS_ANGLES always writes (SOS_ANGLES.F:367-376, 494-506)
-            write_mie_angles(os.path.join(resroot, "SOS", str(p["ficangles_res_mie"]).strip()), nb_mie, os_nb,
-                             str(p["ficangles_user_mie"]).strip())
-            write_used_angles(os.path.join(resroot, "SOS", str(p["ficangles_res_lum"]).strip()), mu, ga, n0, ind_ang, nb_lum,
-                              p["tetas"], os_nb, os_ns, os_nm, str(p["ficangles_user_lum"]).strip())
-            if use_model:
-                write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()), aer_phase, aer_phase["kmat1"],
-                                    aer_phase["kmat2"])
-            elif p["aot_ref"] == 0.0:                 # SOS_AEROSOLS writes an all-zero file for an aerosol-free run
-                z = np.zeros(os_nb + 1)
-                write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()),
-                                    dict(alpha=z, beta=z, gamma=z, zeta=z, a_tronc=0.0, piztr=0.0, piz=0.0))
-            write_result_bin(os.path.join(resroot, "SOS", resbin), rec[0, :nf].cpu().numpy())
-    finally:
+    except BaseException:
         ctx.close()
+        raise
+    pl.bins, pl.aik, pl.band_sharded, pl.tabs_flux = bins, aik, band_sharded, tabs_flux
+    return pl
+
+
+def _trphi_launch(pl, rec0, nf, tau, tauout):
+    """Queue SOS_TRPHI for the azimuths of the view mode; returns the device tensor [nphi][7][W] (no synchronisation)."""
+    phis, pl.rows, pl.phi_fin = _trphi_azimuths(pl.itrphi, pl.p["phios"], pl.p["pas_phi"])
+    return pl.ctx.trphi(rec0, nf, tau, tauout, phis, igli=pl.igli, wind=pl.p["wind"] if pl.igli else 0.0, land=pl.land)
+
+
+def _finish(pl, out, rec0, fin, g=0):
+    """The tail of SOS_PROC (SOS_PROC.F:3755-3874) on the host: the (361,81) tables from sosgpu_trphi's output `out` (host
+    array), fluxes, result files (rank 0 only), the 23-tuple.  rec0: aggregated records [S][3][W] of this wavelength
+    (device); fin: dist.finish_scalars dictionary, g the wavelength's segment in it."""
+    p, n, mu = pl.p, pl.n, pl.mu
+    nf = int(fin["n_orders"][g])
+    tau_agg, ttot_vrai_agg = float(fin["ttot_tronc"][g]), float(fin["ttot_vrai"][g])
+    phi_fin, theta_fin, up, dn = _trphi_pack(n, mu, out, pl.rows, pl.phi_fin)
+    emoins, eplus = float(fin["emoins"][g]), float(fin["eplus"][g])
+    from . import absorption as _abs
+    resbin = str(p["ficsos_res_bin"]).strip()
+    resroot = str(p["resroot"]).strip() if getattr(pl, "writes_files", _dist_rank_world()[0] == 0) else ""
+    if resroot:                                   # SOS_PROC.F:1342-1500: results under RESROOT/SOS
+        os.makedirs(os.path.join(resroot, "SOS"), exist_ok=True)
+        # the two angle files SOS_ANGLES always writes (SOS_ANGLES.F:367-376, 494-506)
+        write_mie_angles(os.path.join(resroot, "SOS", str(p["ficangles_res_mie"]).strip()), pl.nb_mie, pl.os_nb,
+                         str(p["ficangles_user_mie"]).strip())
+        write_used_angles(os.path.join(resroot, "SOS", str(p["ficangles_res_lum"]).strip()), mu, pl.ga, pl.n0, pl.ind_ang,
+                          pl.nb_lum, p["tetas"], pl.os_nb, pl.os_ns, pl.os_nm, str(p["ficangles_user_lum"]).strip())
+        if pl.use_model:
+            write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()), pl.aer_phase, pl.aer_phase["kmat1"],
+                                pl.aer_phase["kmat2"])
+        elif p["aot_ref"] == 0.0:                 # SOS_AEROSOLS writes an all-zero file for an aerosol-free run
+            z = np.zeros(pl.os_nb + 1)
+            write_aerosols_file(os.path.join(resroot, "SOS", str(p["ficgranu"]).strip()),
+                                dict(alpha=z, beta=z, gamma=z, zeta=z, a_tronc=0.0, piztr=0.0, piz=0.0))
+        write_result_bin(os.path.join(resroot, "SOS", resbin), rec0[:nf].cpu().numpy())
     cs = math.cos(math.pi * p["tetas"] / 180.0)
     tdir_tronc = math.exp(-tau_agg / cs)                                          # SOS_PROC.F:3831-3837
     tdir_vrai = math.exp(-ttot_vrai_agg / cs)
     flux_diff_down = emoins + tdir_tronc - tdir_vrai
     flux_down = emoins + tdir_tronc
-    if resroot and want_trans:
+    if resroot and pl.want_trans:
         write_trans_file(os.path.join(resroot, "SOS", str(p["fictrans"]).strip()), p["tetas"], mu, tau_agg, ttot_vrai_agg,
-                         float(fin["tdifmus"][0]), fin["tdifmug"][0])
+                         float(fin["tdifmus"][g]), fin["tdifmug"][g])
     if resroot and str(p["ficflux"]).strip() != "NO_OUTPUT":
-        zal = prep["userprofil"][:, 0] if use_gas else np.linspace(0., 0., _abs.NLEVEL)
+        tl = pl.tabs_flux
+        tabs_flux = np.zeros(_abs.NLEVEL) if tl is None else (tl[-1].cpu().numpy() if hasattr(tl, "cpu") else np.asarray(tl)[-1])
+        zal = pl.prep["userprofil"][:, 0] if pl.use_gas else np.linspace(0., 0., _abs.NLEVEL)
         write_flux_file(os.path.join(resroot, "SOS", str(p["ficflux"]).strip()), p["tetas"], tdir_vrai, flux_diff_down, flux_down,
-                        eplus, zal, tr, p["hr"], ta, ha, tabs_flux)
+                        eplus, zal, pl.tr, p["hr"], pl.ta, pl.ha, tabs_flux)
     ind_angout = np.zeros(81, dtype=np.int32)
-    ind_angout[:n] = ind_ang
+    ind_angout[:n] = pl.ind_ang
     return (n, ind_angout, phi_fin, theta_fin,
             up["sca"], up["i"], up["q"], up["u"], up["ang"], up["rate"], up["lpol"],
             dn["sca"], dn["i"], dn["q"], dn["u"], dn["ang"], dn["rate"], dn["lpol"],
-            tdir_vrai, flux_diff_down, flux_down, eplus, a_tronc if coef_tronca_out is None else coef_tronca_out)
+            tdir_vrai, flux_diff_down, flux_down, eplus, pl.a_tronc if pl.coef_tronca_out is None else pl.coef_tronca_out)
+
+
+def sos_proc(aer_phase=None, device=0, **kw):
+    """Drop-in for `sos.sos_proc(**kwargs)` (f2py of SOS_PROC, SOS_PROC.F:415) on the MI355X hot path.
+    Returns the reference's 23-tuple (names in OUTPUT_NAMES).
+
+    aer_phase (extension, not a reference keyword): dict(alpha, beta, gamma, zeta [OS_NB+1 each], piz, piztr,
+    a_tronc) -- the content of the reference's Aerosols.txt when `-AER.AOTref` > 0 (bypasses the Mie / size-distribution
+    step).  With torch.distributed initialised the call is a collective: the band's CKD bins are sharded over the ranks
+    (one all-reduce) and every rank returns the same outputs."""
+    from .solver import SosBinError
+    pl = _prepare(kw, aer_phase, device, shard_bins=True)
+    try:
+        # one fused solve of the band's bins, one aggregate (+ the all-reduce of a sharded band)
+        try:
+            rec, fin = pl.ctx.solve_band(pl.bins, pl.aik, tdifmug=pl.tdifmug, reduce=pl.band_sharded)
+        except SosBinError as e:
+            raise SosProcError(str(e), ier=-1)
+        out = _trphi_launch(pl, rec[0], int(fin["n_orders"][0]), float(fin["ttot_tronc"][0]), float(fin["tauout"][0]))
+        return _finish(pl, out.cpu().numpy(), rec[0], fin, 0)
+    finally:
+        pl.ctx.close()
 
 
 def sos_proc_many(kwargs_list, n_workers=8, device=0):
@@ -1078,6 +1132,192 @@ def sos_proc_many(kwargs_list, n_workers=8, device=0):
         futs = [ex.submit(one, kw) for kw in kwargs_list]
         concurrent.futures.wait(futs)
     return [f.result() for f in futs]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A whole spectrum through the drop-in (BASELINE config 5: hyperspectral runs)
+# ---------------------------------------------------------------------------------------------------------
+_TABLE_NAMES = (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)     # the fourteen (361,81) tables of the 23-tuple
+
+
+def _compact_outputs(t, nrow):
+    """A 23-tuple without the zero padding of its fixed-size tables (what travels between ranks): the (361,81) tables cut to
+    the `nrow` azimuth rows and N columns in use."""
+    n = int(t[0])
+    return tuple(np.ascontiguousarray(x[:nrow, :n]) if i in _TABLE_NAMES else x for i, x in enumerate(t)) + (nrow,)
+
+
+def _expand_outputs(c):
+    nrow = c[-1]
+    out = []
+    for i, x in enumerate(c[:-1]):
+        if i in _TABLE_NAMES:
+            full = np.zeros((361, 81))
+            full[:nrow, :x.shape[1]] = x
+            out.append(full)
+        else:
+            out.append(x)
+    return tuple(out)
+
+
+def _gather_results(results, mine, nrows, world):
+    """Every rank receives the 23-tuples of the wavelengths the other ranks computed (all_gather_object of the compacted
+    tuples; the only exchange of a wavelength-partitioned spectrum)."""
+    import torch.distributed as dist
+    part = [(i, _compact_outputs(results[i], nrows[i])) for i in mine]
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
+    for pr in parts:
+        for i, c in pr:
+            if results[i] is None:
+                results[i] = _expand_outputs(c)
+
+
+def spectrum_costs(kwargs_list):
+    """Relative cost of every call of a spectrum, from its keywords alone (no aerosol, surface or profile work): number of CKD
+    bins of the spectral interval (product of the gases' exponential-term counts, read from the CKD table headers -- 1 without
+    gas absorption or in -SOS.AbsModeCKD 2) x dist.bin_cost of the wavelength's scattering optical depth (Rayleigh formula +
+    -AER.AOTref) and a moderate gas column.  Used to deal the wavelengths to the ranks."""
+    from . import absorption as _abs
+    from .dist import bin_cost
+    costs = np.zeros(len(kwargs_list))
+    for i, kw in enumerate(kwargs_list):
+        nb = 1
+        try:
+            if int(kw["absprofil"]) != 7 and int(kw["imode_ckd_calcul"]) == 1:
+                nb = _abs.band_bin_count(kw["wa_simu"], float(kw["nustep"]))
+        except Exception:               # a call that will fail in validation costs nothing; the error is raised by its owner
+            nb = 1
+        tr = kw.get("tr", _D)
+        if tr == _D:
+            tr = rayleigh_optical_thickness(kw["wa_simu"], kw["psurf"]) if kw.get("psurf", _D) != _D and kw.get("wa_simu", _D) != _D else 0.1
+        ta = kw.get("aot_ref", 0.0)
+        ta = 0.0 if ta == _D else ta
+        norders = 3 if ta == 0.0 else 40          # Fourier orders: 3 for a molecular atmosphere (IBORM = 2), tens with aerosols
+        costs[i] = nb * float(bin_cost(tr + ta, 0.5 if nb > 1 else 0.0)) * norders
+    return costs
+
+
+def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None):
+    """A spectrum of sos_proc calls -- one per wavelength, as the reference issues them one after the other
+    (binding/run_sos.py:640-695; the bin loop of each is SOS_PROC.F:3459-3594) -- as ONE pass over the GPU:
+
+      1. the host preparation of every wavelength (parameter checks, angles, aerosol model, gas tables, surface) and the
+         profiles of all its CKD bins on the device (sosgpu_absprofile + sosgpu_profile), nothing waited for;
+      2. ALL bins of ALL wavelengths in one launch of the fused solver per group of wavelengths sharing a kernel variant
+         (direction count, highest Fourier order, surface-matrix flag, level capacity, output level): a device table of the
+         wavelength contexts, every bin carrying the index of its own (sosgpu_ctx_table + sosgpu_os_solve_multi), and one
+         segmented SOS_AGGREGATE;
+      3. one device-to-host copy of the band scalars, the azimuth recompositions (sosgpu_trphi) of every wavelength queued
+         back to back, one copy of their results, and the 23-tuples on the host.
+
+    Outputs are those of `[sos_proc(**kw) for kw in kwargs_list]`, bit for bit (the table form of the kernels computes the same
+    instruction sequence per bin; bands up to 128 bins are aggregated in the reference's serial bin order in both).
+    Wavelengths are processed `chunk` at a time (their source operators are resident together: 32 MB each at N = 41).
+    Calls that need the diffuse transmissions of -SOS.Trans run through the per-wavelength path.
+
+    With torch.distributed initialised (one process per GPU) the WAVELENGTHS are dealt to the ranks by cost
+    (spectrum_costs, dist.balanced_shards) -- no bin of a band leaves its rank, so there is no all-reduce, only the gather of
+    the results ("partition by wavelength first"): gather=True returns the full list on every rank
+    (all_gather_object of the compacted tuples), gather=False returns None in the slots of other ranks.  Result files of a
+    call (-SOS_Main.ResRoot) are written by the rank that owns it.
+    aer_phases: optional list parallel to kwargs_list of `aer_phase` dictionaries (see sos_proc) or None.
+    timings: optional dict, filled with host-side phase times in seconds (prepare, solve_launch, wait, trphi, finish)."""
+    import time
+    import torch
+    from . import capi
+    from .solver import ContextTable, SosBinError, concat_bins, solve_spectrum
+    from . import dist as _dist
+    capi.lib()
+    nwl = len(kwargs_list)
+    if aer_phases is None:
+        aer_phases = [None] * nwl
+    if len(aer_phases) != nwl:
+        raise ValueError("aer_phases must be parallel to kwargs_list")
+    rank, world = _dist_rank_world()
+    if world > 1:
+        mine = [int(i) for i in _dist.balanced_shards(spectrum_costs(kwargs_list), world)[rank]]
+    else:
+        mine = list(range(nwl))
+    results = [None] * nwl
+    nrows = {}
+    tm = dict(prepare=0.0, solve_launch=0.0, wait=0.0, trphi=0.0, finish=0.0)
+    dev = torch.device("cuda", device)
+    for c0 in range(0, len(mine), max(1, int(chunk))):
+        idx = mine[c0:c0 + max(1, int(chunk))]
+        plans = []
+        try:
+            t0 = time.perf_counter()
+            for i in idx:
+                pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False)
+                pl.writes_files = True
+                pl.index = i
+                plans.append(pl)
+            t1 = time.perf_counter()
+            tm["prepare"] += t1 - t0
+            # --- groups of wavelengths one launch can cover
+            groups = collections.OrderedDict()
+            single = []
+            for pl in plans:
+                b = pl.bins
+                if pl.tdifmug is not None or b["nb"] == 0 or not hasattr(b.get("scal"), "device"):
+                    single.append(pl)
+                    continue
+                key = (pl.n, pl.ctx.smax, pl.ctx.os_nb, bool(pl.ctx._rsurf is not None), b["lp"], b["jout"] is not None)
+                groups.setdefault(key, []).append(pl)
+            solved = []                       # (plans, rec [nw][S][3][W], scal [nw][10+N]) device tensors
+            for key, gp in groups.items():
+                if len(gp) == 1:
+                    single.append(gp[0])
+                    continue
+                table = ContextTable([pl.ctx for pl in gp])
+                bins, cob, seg = concat_bins([pl.bins for pl in gp])
+                aik = torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])).to(dev)
+                rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)
+                solved.append((gp, rec, scal, table))
+            for pl in single:
+                out = pl.ctx.solve(pl.bins, pl.ctx.alloc_outputs(pl.bins["nb"], zero=False))
+                rec, scal = pl.ctx.aggregate(out, pl.aik, scal=pl.bins.get("scal"), tdifmug=pl.tdifmug)
+                solved.append(([pl], rec, scal, None))
+            t2 = time.perf_counter()
+            tm["solve_launch"] += t2 - t1
+            # --- one copy of all band scalars (waits for the solves), then every azimuth recomposition back to back
+            scal_all = torch.cat([s.reshape(-1) for _, _, s, _ in solved]).cpu().numpy()
+            t3 = time.perf_counter()
+            tm["wait"] += t3 - t2
+            outs, pos = [], 0
+            for gp, rec, scal, _ in solved:
+                sw = scal.shape[1]
+                fin = _dist.finish_scalars(scal_all[pos:pos + len(gp) * sw].reshape(len(gp), sw))
+                pos += len(gp) * sw
+                for g, pl in enumerate(gp):
+                    if fin["min_orders"][g] < 0:
+                        raise SosProcError("SOS_OS: wavelength %d (%r microns) holds a malformed bin (NT outside 1..CTE_OS_NT or "
+                                           "IBORM out of range)" % (pl.index, pl.p["wa_simu"]), ier=-1)
+                    pl.fin, pl.g, pl.rec0 = fin, g, rec[g]
+                    outs.append(_trphi_launch(pl, rec[g], int(fin["n_orders"][g]), float(fin["ttot_tronc"][g]),
+                                              float(fin["tauout"][g])))
+            flat = torch.cat([o.reshape(-1) for o in outs]).cpu().numpy()
+            t4 = time.perf_counter()
+            tm["trphi"] += t4 - t3
+            pos, k = 0, 0
+            for gp, _, _, _ in solved:
+                for pl in gp:
+                    cnt = outs[k].numel()
+                    results[pl.index] = _finish(pl, flat[pos:pos + cnt].reshape(outs[k].shape), pl.rec0, pl.fin, pl.g)
+                    nrows[pl.index] = len(pl.rows)
+                    pos += cnt
+                    k += 1
+            tm["finish"] += time.perf_counter() - t4
+        finally:
+            torch.cuda.current_stream(dev).synchronize()      # the table launches read every context's operators
+            for pl in plans:
+                pl.ctx.close()
+    if timings is not None:
+        timings.update(tm)
+    if world > 1 and gather:
+        _gather_results(results, mine, nrows, world)
+    return results
 
 
 def write_trans_file(path, tetas, mu, ttot_tronc, ttot_vrai, tdifmus, tdifmug):

@@ -78,8 +78,9 @@ class SosContext:
                 r = torch.from_numpy(np.ascontiguousarray(rsurf, dtype=np.float32)).to(self.device)
             if tuple(r.shape) != (self.smax + 1, 9, self.n, self.n):
                 raise ValueError("rsurf shape %s != %s" % (tuple(r.shape), (self.smax + 1, 9, self.n, self.n)))
-            self._rsurf = r
-            capi.check(L.sosgpu_set_surface_matrices(self._h, _ptr(r)), "sosgpu_set_surface_matrices")
+            self._rsurf = r               # kept alive: the packing below is only queued
+            capi.check(L.sosgpu_set_surface_matrices_async(self._h, _ptr(r), self._stream()),
+                       "sosgpu_set_surface_matrices_async")
         self.noyaux()
 
     def _stream(self):
@@ -321,9 +322,9 @@ class SosContext:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            torch.cuda.synchronize(self.device)
-            capi.lib().sosgpu_destroy(self._h)
+            capi.lib().sosgpu_destroy(self._h)            # waits for the streams this context's work was queued on
             self._h = C.c_void_p()
+            self._rsurf = None
 
     def __del__(self):
         try:

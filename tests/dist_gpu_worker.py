@@ -44,21 +44,20 @@ def main():
     aik = rng.uniform(0.1, 1.0, nb); aik /= aik.sum()
     tdif = rng.uniform(0.0, 1.0, (nb, len(c["rmu"])))
     cx = pkg.SosContext(c["rmu"], c["ga"], c["n0"], *c["coefs"], iborm_max=c["iborm"], ro=0.1, device=dev)
-    lo, hi = D.shard_range(nb, rank, world)
-    sl = slice(lo, hi)
+    # the band is dealt to the ranks by cost (the drop-in's partition, dist.balanced_shards): thickest gas columns first,
+    # every rank's bins in their original order; a rank may own no bin
+    costs = D.bin_cost(h[:, -1] * 0 + 0.3948, np.maximum(h[:, -1] - 0.3948, 0.0))
+    sl = D.balanced_shards(costs, world)[rank]
+    lo, hi = (int(sl[0]), int(sl[-1]) + 1) if len(sl) else (0, 0)
     bins = cx.upload_bins(h[sl], xdel[sl], ydel[sl])
     rec, fin = cx.solve_band(bins, torch.as_tensor(aik[sl], device=cx.device),
                              tdifmug=torch.as_tensor(tdif[sl], device=cx.device))
     torch.cuda.synchronize()
     res = {"rank": rank, "world": world, "shard": [lo, hi]}
-    if rank == 0:
-        # the same band without sharding (no process group involved: group of one rank)
-        solo = dist.new_group([0]) if world > 1 else None
-    else:
-        solo = None
     if world > 1:
         dist.barrier()
     if rank == 0:
+        # the same band without sharding: a plain solve + aggregate of all bins, no collective involved
         allb = cx.upload_bins(h, xdel, ydel)
         out = cx.solve(allb)
         rec1, scal1 = cx.aggregate(out, torch.as_tensor(aik, device=cx.device), tdifmug=torch.as_tensor(tdif, device=cx.device))

@@ -2,6 +2,7 @@
 fabricated partials on gloo).  torch.distributed.run starts the ranks; tests/dist_gpu_worker.py is one rank."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -10,12 +11,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _run(world, backend, tmp_path, bins):
     out = str(tmp_path / "res.json")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "--backend", backend, "--bins", str(bins),
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "--backend", backend, "--bins", str(bins),
            "--out", out]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
@@ -57,7 +66,7 @@ def test_sos_proc_sharded(tmp_path, case, world):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", "29549", os.path.join(ROOT, "tests", "dist_proc_worker.py"), "--case", case, "--out", out]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_proc_worker.py"), "--case", case, "--out", out]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     r = json.load(open(out))

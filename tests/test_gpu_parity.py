@@ -425,4 +425,9 @@ def test_streamed_order_parallel_form_equals_per_bin_launch(gpu_pkg, monkeypatch
     rs, rb = out_s["rec"].cpu().numpy(), out_b["rec"].cpu().numpy()
     for i in range(nb):
         assert np.array_equal(rs[i, :max(no[i], 0)], rb[i, :max(no[i], 0)]), i
+    # include/sosgpu.h: only orders 0 .. norders-1 hold records -- the zero-filled buffer of solve() stays zero beyond them in
+    # BOTH forms (the order-parallel form computes orders past the stop and clears their rows again)
+    assert np.array_equal(rs, rb)
+    for i in range(nb):
+        assert not rs[i, max(no[i], 0):].any(), i
     cx.close()
