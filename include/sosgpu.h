@@ -10,9 +10,10 @@
  *     without waiting; their d_ inputs must have been produced on `stream` (or be complete) and must stay allocated
  *     until the queued work has run;
  *   - host-synchronous entry points without a stream argument (sosgpu_create, sosgpu_set_surface_matrices,
- *     sosgpu_ctx_table, sosgpu_noyaux_fetch, sosgpu_os_flops) move their data on a private non-blocking stream of the
- *     calling host thread and wait for that stream only; the last two first wait for the streams THIS context's work
- *     was queued on.  What they wrote is complete on return, so work queued afterwards on any stream sees it;
+ *     sosgpu_noyaux_fetch, sosgpu_os_flops) move their data on a private non-blocking stream of the calling host thread
+ *     and wait for that stream only; the last two first wait for the streams THIS context's work was queued on.  They
+ *     write only memory the library owns (never a caller's buffer, which the caller's other queued work may still be
+ *     using), and what they wrote is complete on return, so work queued afterwards on any stream sees it;
  *   - a context may be used from one host thread at a time; different contexts may be driven from different host
  *     threads on different streams concurrently (run_sos.sos_proc_many), and no call waits for another thread's work;
  *   - sosgpu_destroy waits for the streams the context's own work was queued on, nothing else.
@@ -135,9 +136,11 @@ int  sosgpu_trim(void);
  * of the 512 workgroups the chip hosts).  The reference runs SOS_PROC once per wavelength (binding/run_sos.py:640); here the
  * bin loops SOS_PROC.F:3459-3594 of nctx wavelengths are concatenated and every bin carries the index of its wavelength.
  *   sosgpu_ctx_table   copies the device-side description of nctx contexts (sosgpu_ctx_table_entry_bytes() each) into the
- *                      caller's device buffer d_table; synchronous.  All contexts must live on one device and agree in
+ *                      caller's device buffer d_table, ordered on `stream` (nothing is waited for: the copy comes from a pinned
+ *                      block ctxs[0] keeps until it is destroyed).  All contexts must live on one device and agree in
  *                      N, iborm_max and IMAT_SURF (E_ARG otherwise).  The table refers to the contexts' operator tables: it
- *                      stays valid until one of them is destroyed or has sosgpu_set_surface_matrices called again.
+ *                      stays valid until one of them is destroyed or has sosgpu_set_surface_matrices called again -- a
+ *                      destroyed context's memory is recycled at once, so wait for the launches that use the table first.
  *   sosgpu_os_solve_multi   sosgpu_os_solve with d_ctx_of_bin[nb] (int32, 0..nctx-1): bin b is solved with the operators of
  *                      table entry d_ctx_of_bin[b].  `cx` is any context of the table (it provides the variant selection, the
  *                      streamed variant's scratch and the timing events).  d_order[nb] (int32, a permutation of 0..nb-1) or
@@ -145,7 +148,7 @@ int  sosgpu_trim(void);
  *                      bins first shortens the tail of the launch while the bins stay grouped by wavelength in memory.
  *                      All other arguments as sosgpu_os_solve; feed sosgpu_aggregate with one segment per wavelength. */
 size_t sosgpu_ctx_table_entry_bytes(void);
-int  sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table);
+int  sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table, void *stream);
 int  sosgpu_os_solve_multi(sosgpu_ctx *cx, const void *d_table, const int32_t *d_ctx_of_bin, const int32_t *d_order, int nb, int lp,
                            const int32_t *d_nt, const int32_t *d_iborm, const double *d_prof, const int32_t *d_jout,
                            const double *d_zz, double *d_rec, int32_t *d_norders, int32_t *d_iglast, double *d_flux,

@@ -514,3 +514,56 @@ def sos_absprofile(prep, ik, absprofil=1):
 
     _big_stack_call(call)
     return tau, ier.value
+
+
+MIE_NBMU_MAX = 100      # CTE_MIE_NBMU_MAX, SOS.h:457
+
+
+def read_mie_file(path):
+    """Records of a MIE file the reference wrote (SOS_MIE.F:391, 912): header RN, IN, ALPHAF (double), MIE_NBMU (int32), then per
+    size parameter REAL*4 alpha, Qext, Qsca, DOUBLE G, REAL*4 Imie / Qmie / Umie (-NBMU:NBMU).  Returns the dictionary layout
+    of the product's aerosols.mie_records."""
+    raw = open(path, "rb").read()
+    m = int(np.frombuffer(raw[:4], "<i4")[0])
+    rn, in_, alphaf = np.frombuffer(raw[4:28], "<f8")
+    nbmu = int(np.frombuffer(raw[28:32], "<i4")[0])
+    assert m == 28
+    w = 2 * nbmu + 1
+    pos = 4 + m + 4
+    rl = 12 + 8 + 3 * w * 4
+    a, qe, qs, g, im, qm, um = [], [], [], [], [], [], []
+    while pos < len(raw):
+        n = int(np.frombuffer(raw[pos:pos + 4], "<i4")[0])
+        assert n == rl, (n, rl)
+        body = raw[pos + 4:pos + 4 + n]
+        f = np.frombuffer(body[:12], "<f4")
+        a.append(f[0]); qe.append(f[1]); qs.append(f[2])
+        g.append(np.frombuffer(body[12:20], "<f8")[0])
+        ph = np.frombuffer(body[20:], "<f4").reshape(3, w)
+        im.append(ph[0]); qm.append(ph[1]); um.append(ph[2])
+        pos += n + 8
+    return dict(rn=float(rn), in_=float(in_), alphaf=float(alphaf), nbmu=nbmu, alpha=np.array(a, np.float32),
+                qext=np.array(qe, np.float32), qsca=np.array(qs, np.float32), g=np.array(g), imie=np.array(im, np.float32),
+                qmie=np.array(qm, np.float32), umie=np.array(um, np.float32))
+
+
+def sos_mie(xmu, rn, in_, alphao, alphaf, workdir):
+    """SOS_MIE (SOS_MIE.F:205) for the angle set xmu[-N:N] (2N+1 cosines, entry N unused): the records of the MIE file it
+    writes into `workdir`."""
+    w = len(xmu)
+    n = (w - 1) // 2
+    rmu = np.zeros(2 * MIE_NBMU_MAX + 1)
+    rmu[MIE_NBMU_MAX - n:MIE_NBMU_MAX + n + 1] = xmu
+    chr_ = np.zeros(2 * MIE_NBMU_MAX + 1)
+    path = os.path.join(workdir, "MIE_TEST")
+    f1, f2 = _fstr(path), _fstr("NO_LOG_FILE")
+    ier = C.c_int32(0)
+    nb, a0, a1, r, i = C.c_int32(n), C.c_double(alphao), C.c_double(alphaf), C.c_double(rn), C.c_double(in_)
+
+    def call():
+        lib().sos_mie_(C.byref(nb), _p(rmu), _p(chr_), C.byref(r), C.byref(i), C.byref(a0), C.byref(a1), f1, f2, C.byref(ier),
+                       C.c_size_t(LENFIC2), C.c_size_t(LENFIC2))
+
+    _big_stack_call(call)
+    assert ier.value == 0, ier.value
+    return read_mie_file(path)

@@ -87,7 +87,7 @@ def lib():
         L.sosgpu_ctx_table_entry_bytes.restype = C.c_size_t
         L.sosgpu_ctx_table_entry_bytes.argtypes = []
         L.sosgpu_ctx_table.restype = i32
-        L.sosgpu_ctx_table.argtypes = [C.POINTER(vp), i32, vp]
+        L.sosgpu_ctx_table.argtypes = [C.POINTER(vp), i32, vp, vp]
         L.sosgpu_os_solve_multi.restype = i32
         L.sosgpu_os_solve_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sosgpu_aggregate.restype = i32

@@ -32,6 +32,7 @@ struct sosgpu_ctx {
     bool timed;
     hipStream_t last_stream;
     std::vector<hipStream_t> used_streams;   // every stream a solve / table build of this context was queued on
+    std::vector<void *> host_staging;        // pinned host blocks of queued copies (sosgpu_ctx_table), freed by sosgpu_destroy
     int nt_max_hint;
     double ind_surf;
     unsigned long long *phase;   // diagnostic phase-cycle buffer (sosgpu_debug_phase_buffer), else null
@@ -398,6 +399,7 @@ extern "C" int sosgpu_destroy(sosgpu_ctx *cx)
     // teardown: nothing useful can be done with a failing free, errors are deliberately dropped
     (void)hipSetDevice(cx->device);
     (void)sync_ctx_streams(cx);        // solves / table builds of this context may still be running, on any of its streams
+    for (void *h : cx->host_staging) (void)hipHostFree(h);
     for (size_t i = 0; i < cx->allocs.size(); i++) mem_give(cx->device, cx->allocs[i], cx->alloc_cls[i]);
     if (cx->scratch) pool_give(cx->device, cx->scratch, cx->scratch_doubles);
     if (cx->ev0) (void)hipEventDestroy(cx->ev0);
@@ -669,11 +671,17 @@ extern "C" int sosgpu_os_solve(sosgpu_ctx *cx, int nb, int lp, const int32_t *d_
 
 extern "C" size_t sosgpu_ctx_table_entry_bytes(void) { return sizeof(SosDev); }
 
-extern "C" int sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table)
+extern "C" int sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table, void *stream)
 {
     if (!ctxs || nctx < 1 || !d_table || !ctxs[0]) return SOSGPU_E_ARG;
     const SosDev &a = ctxs[0]->d;
-    std::vector<SosDev> tab((size_t)nctx);
+    // The table is copied on the caller's stream -- d_table is the caller's memory and may still be read by work queued there
+    // (a buffer the caller's allocator has just recycled) -- from a pinned staging block the first context keeps until it is
+    // destroyed, so nothing is waited for.
+    HIPCHK(hipSetDevice(ctxs[0]->device));
+    SosDev *tab = nullptr;
+    HIPCHK(hipHostMalloc((void **)&tab, (size_t)nctx * sizeof(SosDev), hipHostMallocDefault));
+    ctxs[0]->host_staging.push_back(tab);
     for (int i = 0; i < nctx; i++) {
         if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) return SOSGPU_E_ARG;
         const SosDev &d = ctxs[i]->d;
@@ -684,11 +692,8 @@ extern "C" int sosgpu_ctx_table(sosgpu_ctx *const *ctxs, int nctx, void *d_table
         if (d.imat_surf && !d.mp_gnd) return SOSGPU_E_ARG;
         tab[i] = d;
     }
-    HIPCHK(hipSetDevice(ctxs[0]->device));
-    hipStream_t us = util_stream(ctxs[0]->device);
-    if (!us) return SOSGPU_E_HIP;
-    HIPCHK(hipMemcpyAsync(d_table, tab.data(), (size_t)nctx * sizeof(SosDev), hipMemcpyHostToDevice, us));
-    HIPCHK(hipStreamSynchronize(us));
+    HIPCHK(hipMemcpyAsync(d_table, tab, (size_t)nctx * sizeof(SosDev), hipMemcpyHostToDevice, (hipStream_t)stream));
+    note_stream(ctxs[0], (hipStream_t)stream);
     return SOSGPU_OK;
 }
 

@@ -147,17 +147,13 @@ def sos_proc_kwargs(dict_sos, trace=True):
 # file formats either side of the hot path
 # ---------------------------------------------------------------------------------------------------------
 def fortran_e(x, width, digits):
-    """Fortran Ew.d edit descriptor: 0.ddddddddE+ee, right-justified in `width` columns."""
+    """Fortran Ew.d edit descriptor: 0.ddddddddE+ee, right-justified in `width` columns.  The digits come from the correctly
+    rounded decimal conversion of the binary value (C's %e, as the Fortran runtime's), shifted to the 0.d form."""
     if x == 0.0:
-        body = "0." + "0" * digits + "E+00"
+        body = ("-" if math.copysign(1.0, x) < 0 else "") + "0." + "0" * digits + "E+00"
     else:
-        e = int(math.floor(math.log10(abs(x)))) + 1
-        m = abs(x) / 10.0 ** e
-        ms = "%.*f" % (digits, m)
-        if ms.startswith("1."):                  # mantissa rounded up to 1.000...: renormalise
-            e += 1
-            ms = "%.*f" % (digits, m / 10.0)
-        body = ("-" if x < 0 else "") + ms + "E%+03d" % e
+        m, e = ("%.*e" % (digits - 1, abs(x))).split("e")
+        body = ("-" if x < 0 else "") + "0." + m.replace(".", "") + "E%+03d" % (int(e) + 1)
     return body.rjust(width)
 
 
@@ -1240,6 +1236,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     else:
         mine = list(range(nwl))
     results = [None] * nwl
+    debug = bool(os.environ.get("SOS_SPECTRUM_DEBUG"))
     nrows = {}
     tm = dict(prepare=0.0, solve_launch=0.0, wait=0.0, trphi=0.0, finish=0.0)
     dev = torch.device("cuda", device)
@@ -1250,6 +1247,9 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
             t0 = time.perf_counter()
             for i in idx:
                 pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False)
+                if debug:
+                    torch.cuda.synchronize(dev)
+                    print("[sos_spectrum] prepared", i, flush=True)
                 pl.writes_files = True
                 pl.index = i
                 plans.append(pl)
@@ -1260,7 +1260,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
             single = []
             for pl in plans:
                 b = pl.bins
-                if pl.tdifmug is not None or b["nb"] == 0 or not hasattr(b.get("scal"), "device"):
+                if pl.tdifmug is not None or b["nb"] == 0 or not isinstance(b.get("scal"), torch.Tensor):
                     single.append(pl)
                     continue
                 key = (pl.n, pl.ctx.smax, pl.ctx.os_nb, bool(pl.ctx._rsurf is not None), b["lp"], b["jout"] is not None)
@@ -1273,7 +1273,12 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 table = ContextTable([pl.ctx for pl in gp])
                 bins, cob, seg = concat_bins([pl.bins for pl in gp])
                 aik = torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])).to(dev)
+                if debug:
+                    print("[sos_spectrum] group", key, "wavelengths", [pl.index for pl in gp], "bins", bins["nb"], flush=True)
                 rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)
+                if debug:
+                    torch.cuda.synchronize(dev)
+                    print("[sos_spectrum]   done", flush=True)
                 solved.append((gp, rec, scal, table))
             for pl in single:
                 out = pl.ctx.solve(pl.bins, pl.ctx.alloc_outputs(pl.bins["nb"], zero=False))
@@ -1367,6 +1372,128 @@ def write_result_bin(path, rec):
             payload = np.concatenate([rec[s, 1], rec[s, 2], rec[s, 0]]).tobytes()
             m = np.array([len(payload)], "<i4").tobytes()
             f.write(m + payload + m)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SOS_Up.txt / SOS_Down.txt as the reference's command-line program writes them (SOS_ABS_MAIN.F:2250-2444)
+# ---------------------------------------------------------------------------------------------------------
+_SEP102 = "#" + "-" * 101
+# (text, width of the `(Aw)` edit descriptor it is written with): the Fortran source is UTF-8, so the degree sign counts
+# two bytes and the two "180 deg / 0 deg" lines lose their last character -- part of the file format as shipped
+_HDR_COLS = [("#   VZA     :  Viewing Zenith Angle (in degrees)", 48), ("#   SCA_ANG :  Scattering angle (in degrees)", 44),
+             ("#   I       :  Stokes parameter I at output altitude z (in sr-1)", 64),
+             ("#              normalised to the extraterrestrial solar irradiance (PI * L(z) / Esun)", 85),
+             ("#   Q       :  Stokes parameter Q at output altitude z (in sr-1)", 64),
+             ("#              normalised to the extraterrestrial solar irradiance", 66),
+             ("#   U       :  Stokes parameter U at output altitude z (in sr-1)", 64),
+             ("#              normalised to the extraterrestrial solar irradiance ", 66),
+             ("#   POL_ANG :  Polarization angle (in degrees).  Note: if undefined the value is -999.00", 88),
+             ("#   POL_RATE:  Degree of polarization (in %)", 44),
+             ("#   IPOL    :  Polarized intensity at level z (in sr-1)", 55),
+             ("#              normalised to the extraterrestrial solar irradiance (PI * Lpol(z) / Esun)", 88)]
+_SAT_180 = ("#        180° <-> Satellite and Sun in the same half-plane", 58)
+_SAT_0 = ("#          0° <-> Satellite and Sun in opposite half-planes with respect to the zenith direction", 96)
+
+
+def _fmt_a(text, width):
+    """Fortran `(Aw)` of a character constant: the first w BYTES of the UTF-8 source text when it is longer, right-justified in w
+    columns when shorter; list-directed trailing blanks are kept by the runtime, not added here (flang trims none)."""
+    b = text.encode("utf-8")
+    return (b" " * (width - len(b)) + b) if len(b) < width else b[:width]
+
+
+def main_output_header(itrphi, updown, zalt, phios=0.0):
+    """SOS_OUTPUT_HEADER (fixed azimuth, SOS_TRPHI.F:1570-1680) / SOS_OUTPUT_HEADER_POLAR_DIAG (:1705-1796) as bytes."""
+    up = updown == 1
+    lines = []
+    if itrphi == 1:
+        lines.append(_fmt_a("# UPWARD RADIANCE FIELD VERSUS THE VIEWING ZENITH ANGLE", 55) if up else
+                     _fmt_a("# DOWNWARD RADIANCE FIELD VERSUS THE VIEWING ZENITH ANGLE", 57))
+        lines += [_fmt_a("# (RELATIVE AZIMUTH AND ALTITUDE ARE FIXED)", 43), _fmt_a(_SEP102, 102),
+                  _fmt_a("# Relative azimuth (degrees) :", 30), b"#", _fmt_a("#      Relative azimuth convention :", 36)]
+        if up:
+            lines += [_fmt_a(*_SAT_180), _fmt_a(*_SAT_0)]
+        else:
+            lines += [_fmt_a("#        180° <-> Viewing direction and Sun in the same half-plane", 66),
+                      _fmt_a("#          0° <-> Viewing direction and Sun in opposite half-planes with respect to the zenith "
+                             "direction", 104)]
+        lines += [b"#", _fmt_a("#      Simulated relative azimuth (degrees) :", 45),
+                  _fmt_a("#          for VZA < 0 (sign convention):", 41) + b" " + ("%7.3f" % (phios + 180.0)).encode(),
+                  _fmt_a("#          for VZA > 0 (sign convention):", 41) + b" " + ("%7.3f" % phios).encode(), b"#"]
+    else:
+        lines.append(_fmt_a("#UPWARD RADIANCE FIELD VERSUS THE AZIMUTH ANGLE AND VIEWING ZENITH ANGLE", 72) if up else
+                     _fmt_a("#DOWNWARD RADIANCE FIELD VERSUS THE AZIMUTH ANGLE AND VIEWING ZENITH ANGLE", 74))
+        lines += [_fmt_a("#(ALTITUDE FIXED)", 17), _fmt_a(_SEP102, 102), _fmt_a("# Relative azimuth convention :", 31),
+                  _fmt_a(*_SAT_180), _fmt_a(*_SAT_0), b"#"]
+    lines += [_fmt_a("# Value of the selected altitude for the output (km) :", 54) + b" " + ("%7.3f" % zalt).encode(), b"#",
+              _fmt_a("# Columns parameters :", 22)]
+    if itrphi != 1:
+        lines.append(_fmt_a("#   PHI     :  Relative azimuth Angle (in degrees)", 50))
+    lines += [_fmt_a(t, w) for t, w in _HDR_COLS]
+    lines.append(_fmt_a(_SEP102, 102))
+    if itrphi == 1:
+        lines += [_fmt_a("#   VZA     SCA_ANG       I              Q              U         POL_ANG  POL_RATE    IPOL", 91),
+                  _fmt_a("#(degrees) (degrees)    (sr-1)         (sr-1)         (sr-1)      (degrees)  (%)      (sr-1)", 92)]
+    else:
+        lines += [_fmt_a("#   PHI      VZA     SCA_ANG        I              Q              U       POL_ANG  POL_RATE    IPOL", 99),
+                  _fmt_a("#(degrees) (degrees) (degrees)    (sr-1)         (sr-1)         (sr-1)    (degrees)  (%)      (sr-1)", 100)]
+    return b"".join(ln + b"\n" for ln in lines)
+
+
+def _f7_2(x):
+    s = "%7.2f" % x
+    return s if len(s) == 7 else "*" * 7                       # Fw.d overflow
+
+
+def write_main_output(path_up, path_down, outputs, itrphi, phios, pas_phi, zout, user_up=None, user_down=None):
+    """The two ASCII result files of the reference's command-line program, byte for byte: headers of SOS_OUTPUT_HEADER*,
+    then format 55 `2(2X,F7.2),2X,3(E13.6,2X),2(F7.2,2X),E13.6` (fixed azimuth: the phi + 180 half plane with negated zenith
+    angles in reversed order, then the phi half plane, SOS_ABS_MAIN.F:2304-2405) or format 56
+    `3(2X,F7.2),1X,3(E13.6,2X),2(1X,F7.2),E13.6` (polar diagram, :2450-2496).  outputs: the 23-tuple of sos_proc.
+    user_up / user_down: optional paths of the -SOS.ResFileUp.UserAng / -SOS.ResFileDown.UserAng files (user angles only,
+    IND_ANGOUT = 1).  One quirk of the reference is kept: in the polar diagram the SCA_ANG column of the UPWARD file is read
+    from row IPHI (the azimuth in degrees) of the table instead of the azimuth's row IP (SOS_ABS_MAIN.F:2466) -- with
+    -SOS.View.Dphi > 1 it holds another azimuth's angle, or 0."""
+    (nblum, ind_ang, phi, vza, sca_up, i_up, q_up, u_up, ang_up, rate_up, lpol_up,
+     sca_dn, i_dn, q_dn, u_dn, ang_dn, rate_dn, lpol_dn) = outputs[:18]
+    zal_up, zal_dn = (CTE_TOA_ALT, 0.0) if zout == -1 else (zout, zout)
+    up = [main_output_header(itrphi, 1, zal_up, phios)]
+    dn = [main_output_header(itrphi, 2, zal_dn, phios)]
+    uu, ud = list(up), list(dn)
+
+    def rec55(th, sca, xi, xq, xu, xan, tpol, lpol):
+        return ("  %s  %s  %s  %s  %s  %s  %s  %s\n" % (_f7_2(th), _f7_2(sca), fortran_e(xi, 13, 6), fortran_e(xq, 13, 6),
+                                                      fortran_e(xu, 13, 6), _f7_2(xan), _f7_2(tpol), fortran_e(lpol, 13, 6))).encode()
+
+    def rec56(ph, th, sca, xi, xq, xu, xan, tpol, lpol):
+        return ("  %s  %s  %s %s  %s  %s   %s %s%s\n" % (_f7_2(ph), _f7_2(th), _f7_2(sca), fortran_e(xi, 13, 6), fortran_e(xq, 13, 6),
+                                                        fortran_e(xu, 13, 6), _f7_2(xan), _f7_2(tpol), fortran_e(lpol, 13, 6))).encode()
+
+    if itrphi == 1:
+        for row, order, sign in ((0, range(nblum - 1, -1, -1), -1.0), (1, range(nblum), 1.0)):
+            for j in order:
+                a = rec55(sign * vza[j], sca_up[row, j], i_up[row, j], q_up[row, j], u_up[row, j], ang_up[row, j], rate_up[row, j],
+                          lpol_up[row, j])
+                b = rec55(sign * vza[j], sca_dn[row, j], i_dn[row, j], q_dn[row, j], u_dn[row, j], ang_dn[row, j], rate_dn[row, j],
+                          lpol_dn[row, j])
+                up.append(a); dn.append(b)
+                if ind_ang[j] == 1:
+                    uu.append(a); ud.append(b)
+    else:
+        for ip, iphi in enumerate(range(0, 361, int(pas_phi))):
+            for j in range(nblum):
+                rest = (i_up[ip, j], q_up[ip, j], u_up[ip, j], ang_up[ip, j], rate_up[ip, j], lpol_up[ip, j])
+                up.append(rec56(phi[ip], vza[j], sca_up[iphi, j], *rest))          # row IPHI: the reference's own indexing
+                b = rec56(phi[ip], vza[j], sca_dn[ip, j], i_dn[ip, j], q_dn[ip, j], u_dn[ip, j], ang_dn[ip, j], rate_dn[ip, j],
+                          lpol_dn[ip, j])
+                dn.append(b)
+                if ind_ang[j] == 1:
+                    uu.append(rec56(phi[ip], vza[j], sca_up[ip, j], *rest))
+                    ud.append(b)
+    for path, parts in ((path_up, up), (path_down, dn), (user_up, uu), (user_down, ud)):
+        if path:
+            with open(path, "wb") as f:
+                f.write(b"".join(parts))
 
 
 _HDR_SEP = "#" + "-" * 101 + "\n"

@@ -353,7 +353,7 @@ class ContextTable:
         n = len(self.ctxs)
         self.table = torch.empty(n * int(L.sosgpu_ctx_table_entry_bytes()), dtype=torch.uint8, device=self.device)
         hs = (C.c_void_p * n)(*[cx._h for cx in self.ctxs])
-        capi.check(L.sosgpu_ctx_table(hs, n, _ptr(self.table)), "sosgpu_ctx_table")
+        capi.check(L.sosgpu_ctx_table(hs, n, _ptr(self.table), self.ctxs[0]._stream()), "sosgpu_ctx_table")
 
 
 def concat_bins(bins_list):

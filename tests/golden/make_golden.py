@@ -700,6 +700,65 @@ def gen_profile_layer(index=None):
     np.savez_compressed(os.path.join(HERE, "profile_layer.npz"), **d)
 
 
+# SOS_Up.txt / SOS_Down.txt of the reference's command-line program (SOS_ABS_MAIN.F:2250-2444): one fixed-azimuth run (flat
+# sea, standard output levels, user viewing angles so that the .UserAng files exist) and one polar diagram (Cox-Munk sea,
+# output at 2 km, 45-degree azimuth step).  Both aerosol-free: the same keywords go through sos_proc_ (ctypes) for the 23-tuple.
+MAIN_ASCII_CASES = {
+    "plane": {"-SOS_Main.Wa": 0.550, "-ANG.Rad.NbGauss": 24, "-ANG.Thetas": 35.0, "-SOS.View": 1, "-SOS.View.Phi": 30.0,
+              "-AP.Psurf": 1013.0, "-AP.AerProfile.Type": 1, "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0, "-AP.AbsProfile.Type": 7,
+              "-AER.AOTref": 0.0, "-AER.Waref": 0.550, "-SURF.Type": 2, "-SURF.Ind": 1.34, "-SURF.Alb": 0.03,
+              "-ANG.Rad.UserAngFile": "@GOLDEN/user_angles.txt"},
+    "polar": {"-SOS_Main.Wa": 0.865, "-ANG.Rad.NbGauss": 12, "-ANG.Thetas": 50.0, "-SOS.View": 2, "-SOS.View.Dphi": 45,
+              "-AP.Psurf": 1013.0, "-AP.AerProfile.Type": 1, "-AP.HR": 8.0, "-AP.AerHS.HA": 2.0, "-AP.AbsProfile.Type": 7,
+              "-AER.AOTref": 0.0, "-AER.Waref": 0.865, "-SURF.Type": 1, "-SURF.Ind": 1.34, "-SURF.Alb": 0.0,
+              "-SURF.Glitter.Wind": 5.0, "-SOS.OutputAlt": 2.0},
+}
+
+
+def gen_main_ascii():
+    """Run oracle/_ref/SOS_ABS_MAIN.exe (make -C oracle main) on the MAIN_ASCII_CASES and keep the bytes of the ASCII result
+    files it writes, next to the 23 outputs of sos_proc_ for the same keywords."""
+    import importlib
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    rs = importlib.import_module("radiativetransfer-sos_amd.run_sos")
+    exe = os.path.join(ROOT, "oracle", "_ref", "SOS_ABS_MAIN.exe")
+    for name, user in MAIN_ASCII_CASES.items():
+        tmp = tempfile.mkdtemp(prefix="sosmain_")
+        try:
+            u = resolve_user(dict(user))
+            u.update({"-SOS_Main.ResRoot": tmp, "-AER.DirMie": tmp + "/MIE", "-SURF.Dir": tmp + "/SURF",
+                      "-SOS_Main.Log": "NO_LOG_FILE", "-ANG.Log": "NO_LOG_FILE", "-AP.Log": "NO_LOG_FILE",
+                      "-SOS.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+            args = []
+            for k, v in u.items():
+                args += [k, repr(float(v)) if isinstance(v, float) else str(v)]
+            if "-ANG.Rad.UserAngFile" in u:
+                args += ["-SOS.ResFileUp.UserAng", "SOS_Up_UserAng.txt", "-SOS.ResFileDown.UserAng", "SOS_Down_UserAng.txt"]
+            env = dict(os.environ, SOS_ABS_ROOT="/root/reference")
+            r = subprocess.run("ulimit -s unlimited && exec %s %s" % (exe, " ".join("'%s'" % a for a in args)), shell=True, env=env,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+            d = {"user_json": json.dumps(user)}
+            for key, fn in (("up", "SOS_Up.txt"), ("down", "SOS_Down.txt"), ("up_user", "SOS_Up_UserAng.txt"),
+                            ("down_user", "SOS_Down_UserAng.txt")):
+                f = os.path.join(tmp, "SOS", fn)
+                if os.path.exists(f):
+                    d["file_" + key] = np.frombuffer(open(f, "rb").read(), dtype=np.uint8)
+            shutil.rmtree(tmp, ignore_errors=True)
+            os.makedirs(tmp)
+            kw = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), u), trace=False)
+            out = R.sos_proc(list(kw.items()))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        for nm, v in zip(rs.OUTPUT_NAMES, out):
+            d[nm] = np.asarray(v)
+        np.savez_compressed(os.path.join(HERE, "main_ascii_%s.npz" % name), **d)
+        print("main_ascii", name, {k: len(v) for k, v in d.items() if k.startswith("file_")})
+
+
 def gen_aggregate():
     """SOS_AGGREGATE called once per bin in bin order (the reference appends one all-zero record per call after the
     first; those trailing records are part of the fixture)."""
@@ -763,6 +822,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proc_ckd":
         gen_sos_proc_ckd(sys.argv[2:])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "main_ascii":
+        gen_main_ascii()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "aggregate":
         gen_aggregate()

@@ -141,8 +141,9 @@ def test_angle_and_aerosol_text_files_match_the_reference(pkg, tmp_path):
 
 
 def test_ascii_result_files_layout(pkg, tmp_path):
-    """SOS_Up.txt / SOS_Down.txt (gen_sos_output, restated from binding/run_sos.py:196-317 by reading -- parity unpinned: the
-    reference script imports its f2py extension, which cannot be built here).  Layout checks: fixed-azimuth view = the
+    """SOS_Up.txt / SOS_Down.txt in the layout of the reference's PYTHON front end (gen_sos_output, binding/run_sos.py:196-317;
+    the script itself cannot run here -- it imports its f2py extension -- so its numbers are pinned against the files of the
+    Fortran main in test_main_ascii_writer_reproduces_the_reference_files_byte_for_byte).  Layout: fixed-azimuth view = the
     phi + 180 half plane first (negated zenith angles, descending), then the phi half plane; polar view = one block of NBLUM
     rows per azimuth, ceil(360 / dphi) blocks; numbers in the %13.6e / %7.2f columns of the reference's format strings."""
     rs = pkg.run_sos
@@ -167,6 +168,81 @@ def test_ascii_result_files_layout(pkg, tmp_path):
     assert len(data) == 5 * nbl and lines[0].startswith("#DOWNWARD RADIANCE FIELD")
     assert [float(ln.split()[0]) for ln in data[::nbl]] == [0., 80., 160., 240., 320.]
     assert any("2.5" in ln and "altitude" in ln for ln in lines)
+
+
+MAIN_ASCII = ["plane", "polar"]
+
+
+def _main_ascii_user(g):
+    return {k: (os.path.join(GOLD, v[8:]) if isinstance(v, str) and v.startswith("@GOLDEN/") else v)
+            for k, v in json.loads(str(g["user_json"])).items()}
+
+
+def _data_rows(raw):
+    return np.array([[float(x) for x in ln.split()] for ln in raw.decode("latin-1").splitlines() if not ln.startswith("#")])
+
+
+@pytest.mark.parametrize("name", MAIN_ASCII)
+def test_main_ascii_writer_reproduces_the_reference_files_byte_for_byte(pkg, tmp_path, name):
+    """SOS_Up.txt / SOS_Down.txt (+ the .UserAng pair) as the reference's command-line program writes them
+    (SOS_ABS_MAIN.F:2250-2444, formats 55/56, headers SOS_TRPHI.F:1570-1796): tests/golden/main_ascii_*.npz hold the bytes of
+    the files SOS_ABS_MAIN.exe wrote (make_golden.py main_ascii) and the 23 outputs of the reference's sos_proc_ for the same
+    keywords.  Fed those outputs, run_sos.write_main_output reproduces the files byte for byte -- headers (with the truncated
+    degree-sign lines), F7.2 / E13.6 columns, plane ordering, the row-IPHI quirk of the polar upward file."""
+    rs = pkg.run_sos
+    g = np.load(os.path.join(GOLD, "main_ascii_%s.npz" % name))
+    user = _main_ascii_user(g)
+    out = tuple(g[nm] if g[nm].shape else g[nm][()] for nm in rs.OUTPUT_NAMES)
+    out = (int(out[0]),) + out[1:]
+    pu, pd, uu, ud = (str(tmp_path / f) for f in ("up", "down", "up_user", "down_user"))
+    has_user = "file_up_user" in g.files
+    rs.write_main_output(pu, pd, out, int(user["-SOS.View"]), user.get("-SOS.View.Phi", -999.0), user.get("-SOS.View.Dphi", -999),
+                         float(user.get("-SOS.OutputAlt", -1.0)), uu if has_user else None, ud if has_user else None)
+    for key, path in (("up", pu), ("down", pd)) + ((("up_user", uu), ("down_user", ud)) if has_user else ()):
+        ref = g["file_" + key].tobytes()
+        got = open(path, "rb").read()
+        assert got == ref, (key, [(a, b) for a, b in zip(got.splitlines(), ref.splitlines()) if a != b][:3])
+    assert len(_data_rows(g["file_up"].tobytes())) == (2 * out[0] if name == "plane" else 9 * out[0])
+    # the reference's Python front end formats the same numbers with C-style %13.6e: gen_sos_output's numbers equal the
+    # Fortran file's to the digits both carry
+    rs.gen_sos_output(str(tmp_path), int(user["-SOS.View"]), 1, 0.0, out[0], user.get("-SOS.View.Dphi", -999), out[2], out[3],
+                      out[4], out[5], out[6], out[7], out[8], out[9], out[10])
+    mine = _data_rows(open(tmp_path / "SOS_Up.txt", "rb").read())
+    ref = _data_rows(g["file_up"].tobytes())
+    n = min(len(mine), len(ref))                            # (polar view: the script writes ceil(360/dphi) blocks, the main 360/dphi + 1)
+    assert n >= 8 * out[0] or name == "plane"
+    sca = 2 if name == "polar" else 1
+    cols = [c for c in range(ref.shape[1]) if not (name == "polar" and c == sca)]      # (row-IPHI quirk of the main's SCA_ANG)
+    assert np.allclose(mine[:n][:, cols], ref[:n][:, cols], rtol=2e-6, atol=0.0051)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MAIN_ASCII)
+def test_main_ascii_files_from_the_gpu_run(gpu_pkg, tmp_path, name):
+    """The same files from run_sos.sos_proc on the GPU: headers identical, every data column equal to the reference file's to
+    one unit of its last printed digit (the values agree to 1e-9; a digit flips where the 7th decimal sits on a rounding
+    boundary), and at least 98 % of the lines byte-identical."""
+    rs = gpu_pkg.run_sos
+    g = np.load(os.path.join(GOLD, "main_ascii_%s.npz" % name))
+    user = _main_ascii_user(g)
+    user.update({"-SOS_Main.Log": "NO_LOG_FILE", "-SOS.Flux": "NO_OUTPUT"})
+    out = rs.sos_proc(**rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False))
+    cases.compare_proc_outputs(rs, out, g)
+    pu, pd = str(tmp_path / "up"), str(tmp_path / "down")
+    rs.write_main_output(pu, pd, out, int(user["-SOS.View"]), user.get("-SOS.View.Phi", -999.0), user.get("-SOS.View.Dphi", -999),
+                         float(user.get("-SOS.OutputAlt", -1.0)))
+    for key, path in (("up", pu), ("down", pd)):
+        ref, got = g["file_" + key].tobytes().splitlines(), open(path, "rb").read().splitlines()
+        assert len(ref) == len(got)
+        assert [ln for ln in ref if ln.startswith(b"#")] == [ln for ln in got if ln.startswith(b"#")]
+        same = sum(a == b for a, b in zip(ref, got))
+        assert same >= 0.98 * len(ref), (key, same, len(ref))
+        a, b = _data_rows(b"\n".join(got)), _data_rows(b"\n".join(ref))
+        ncol = a.shape[1]
+        ang = [c for c in range(ncol) if c not in (ncol - 6, ncol - 5, ncol - 4, ncol - 1)]
+        assert np.all(np.abs(a[:, ang] - b[:, ang]) <= 0.0101)                                  # F7.2 columns
+        ecol = [ncol - 6, ncol - 5, ncol - 4, ncol - 1]
+        assert np.all(np.abs(a[:, ecol] - b[:, ecol]) <= 1.01e-6 * np.abs(b[:, ecol]) + 1e-30)  # E13.6 columns
 
 
 RANDOM_CASES = sorted(f[len("sos_proc_"):-4] for f in os.listdir(GOLD) if f.startswith("sos_proc_rand_"))
