@@ -1231,7 +1231,7 @@ extern "C" int sosgpu_mie(int device, int nbmu, const double *xmu, double rn, do
         if (alphas[i] <= lds_alpha) { n_lds = i + 1; alds = alphas[i]; }
     }
     if (2 * amax + 24 > 10000) return SOSGPU_E_UNSUPPORTED;                      // CTE_MIE_DIM, SOS.h:117
-    const size_t nscr = n_lds < nalpha ? mie_scratch_doubles(amax) : 0;
+    const size_t nscr = n_lds < nalpha ? mie_scratch_doubles(amax, nalpha - n_lds) : 0;
     TmpBuf tb(device, (size_t)(W + nalpha + nscr) * sizeof(double) + 64);
     if (!tb.p) return SOSGPU_E_HIP;
     char *buf = (char *)tb.p;

@@ -63,6 +63,6 @@ void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const d
 
 // Mie records of a size-parameter grid (mie.hip): rec[nalpha][4 + 3 (2 nbmu + 1)] floats, g[nalpha]; returns 0, -2 (HIP) or -3
 // (alpha_max beyond the LDS-resident coefficient arrays)
-size_t mie_scratch_doubles(double alpha_max);
+size_t mie_scratch_doubles(double alpha_max, int count);
 int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, const double *d_alphas, int n_lds, double alpha_lds,
                double alpha_max, double *d_scratch, float *d_rec, double *d_g, int32_t *d_err, hipStream_t st);

@@ -160,14 +160,15 @@ __global__ void k_mie(int nbmu, const double *__restrict__ xmu, double rn, doubl
 }
 
 // alphas must ascend (alpha_grid does).  Size parameters whose arrays fit LDS run in the LDS form; the rest in the scratch
-// form with MIE_SLOTS workgroups.  d_scratch: mie_scratch_doubles(alpha_max) doubles (0 when everything fits LDS).
+// form with MIE_SLOTS workgroups.  d_scratch: mie_scratch_doubles(alpha_max, number of scratch-form size parameters) doubles.
 #define MIE_LDS_BYTES (150 * 1024)
 #define MIE_SLOTS 2048
 static int mie_nmax(double alpha) { return (int)(2 * alpha + 24); }
-size_t mie_scratch_doubles(double alpha_max)
+size_t mie_scratch_doubles(double alpha_max, int count)
 {
-    const int nmax = mie_nmax(alpha_max);
-    return (size_t)11 * nmax * sizeof(double) <= MIE_LDS_BYTES ? 0 : (size_t)MIE_SLOTS * 11 * nmax;
+    // (whether a scratch is needed is the caller's split of the grid at its LDS limit, sosgpu_mie: a grid ending between that
+    //  limit, alpha = 850, and the 860 the LDS could hold still runs its tail in the scratch form)
+    return (size_t)std::min(std::max(count, 0), MIE_SLOTS) * 11 * mie_nmax(alpha_max);
 }
 
 int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, const double *d_alphas, int n_lds, double alpha_lds,

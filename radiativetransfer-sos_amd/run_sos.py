@@ -1076,7 +1076,21 @@ def sos_proc(aer_phase=None, device=0, **kw):
     step).  With torch.distributed initialised the call is a collective: the band's CKD bins are sharded over the ranks
     (one all-reduce) and every rank returns the same outputs."""
     from .solver import SosBinError
-    pl = _prepare(kw, aer_phase, device, shard_bins=True)
+    rank, world = _dist_rank_world()
+    pl, err = None, None
+    try:
+        pl = _prepare(kw, aer_phase, device, shard_bins=True)
+    except Exception as e:                         # noqa: BLE001 -- re-raised below, after the ranks have agreed
+        err = e
+    if world > 1:
+        # A failure that strikes one rank only (device memory, a HIP error) must not leave the others waiting in the band's
+        # all-reduce: the ranks agree on an error flag first (one integer, MAX).  Parameter errors are the same on every rank.
+        bad = _any_rank_failed(err is not None, device)
+        if bad and err is None:
+            pl.ctx.close()
+            raise SosProcError("sos_proc: another rank failed while preparing this call", ier=-1)
+    if err is not None:
+        raise err
     try:
         # one fused solve of the band's bins, one aggregate (+ the all-reduce of a sharded band)
         try:
@@ -1089,45 +1103,13 @@ def sos_proc(aer_phase=None, device=0, **kw):
         pl.ctx.close()
 
 
-def sos_proc_many(kwargs_list, n_workers=8, device=0):
-    """A spectrum of independent sos_proc calls (one per wavelength: the reference runs them one after the other,
-    binding/run_sos.py:640) issued from `n_workers` host threads, each on its own HIP stream.  One call spends most of its
-    wall clock waiting for the few bins of its band (a bin is a serial chain of scattering orders: milliseconds on a small
-    fraction of the chip); here the waits of one wavelength overlap the host work and the kernels of the others.  Every call
-    is the unchanged sos_proc -- results are identical to the sequential loop.  Give each call its own `-SOS_Main.ResRoot`
-    when result files are wanted (the file names inside are fixed, as in the reference).  Export GPU_MAX_HW_QUEUES=16 before
-    the first GPU call (solver.solve_many).  Returns the list of 23-tuples in order; the first failing call's exception is
-    raised after all calls have ended."""
-    import concurrent.futures
+def _any_rank_failed(failed, device):
     import torch
-    from . import capi
-    capi.lib()                                             # loaded once, before the threads
-    if not kwargs_list:
-        return []
-    if _dist_rank_world()[1] > 1:
-        raise SosProcError("sos_proc_many: with torch.distributed initialised every sos_proc call is a collective over the "
-                           "ranks (the band's bins are sharded) -- issue the calls one after the other")
-    dev = torch.device("cuda", device)
-    nw = max(1, min(int(n_workers), len(kwargs_list)))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]
-    import threading
-    slot = threading.local()
-    free = list(range(nw))
-    lock = threading.Lock()
-
-    def one(kw):
-        if not hasattr(slot, "i"):
-            with lock:
-                slot.i = free.pop()
-        with torch.cuda.device(dev), torch.cuda.stream(streams[slot.i]):
-            out = sos_proc(device=device, **kw)
-            streams[slot.i].synchronize()
-        return out
-
-    with concurrent.futures.ThreadPoolExecutor(max_workers=nw) as ex:
-        futs = [ex.submit(one, kw) for kw in kwargs_list]
-        concurrent.futures.wait(futs)
-    return [f.result() for f in futs]
+    import torch.distributed as dist
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=torch.device("cuda", device) if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -49,9 +49,10 @@ def test_create_rejects_bad_arguments(pkg):
 
 def test_product_path_has_no_cpu_fallback(pkg):
     """The host driver refuses to run without a GPU instead of silently computing on the CPU."""
+    import pytest
     import torch
     if torch.cuda.is_available():
-        return
+        pytest.skip("a GPU is visible: the refusal only exists on a box without one")
     S = pkg.synth
     mu, w, n0 = S.gauss_angles(8, 35.0)
     al, be, ga, ze = S.hg_phase(16, 0.5)
