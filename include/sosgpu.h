@@ -293,6 +293,18 @@ int  sosgpu_absprofile(int device, int nb, int nlev, int nterm, const int32_t *d
 int  sosgpu_mie(int device, int nbmu, const double *xmu, double rn, double in, int nalpha, const double *alphas,
                 float *d_rec, double *d_g, void *stream);
 
+/* Replaces SOS_GRANU (src/SOS_AEROSOLS.F:4392-4820): the integral of Mie records over a size distribution, on the device -- the
+ * records (2 MB per refractive index at 40 Mie angles) never travel to the host.  The reference reads its MIE file record by
+ * record and accumulates in file order; the kernel adds in record order too (the sums of the Fortran loop term for term).
+ *   d_rec[nalpha][4 + 3 (2 nbmu + 1)]  records as sosgpu_mie wrote them (the reference re-uses a MIE file for every
+ *          wavelength with the same refractive index, angle set and size-parameter range: keep d_rec the same way)
+ *   igranu 1: log-normal distribution, v1 = modal radius (microns), v2 = ln-standard deviation (v3 unused);
+ *          2: Junge's law, v1 = r0, v2 = slope, v3 = rmax;   wa = wavelength (microns);  alphaf = upper limit of the grid
+ *   out[3 + 3 (2 nbmu + 1)] (HOST): extinction and scattering cross sections per particle KMAT1, KMAT2, the number integral
+ *          SOMME_NR, then P11, P12, P33 at the 2 nbmu + 1 angles (normalised as SOS_GRANU leaves them).  Synchronous. */
+int  sosgpu_granu(int device, int nbmu, int nalpha, const float *d_rec, int igranu, double v1, double v2, double v3,
+                  double wa, double alphaf, double *out, void *stream);
+
 /* Diagnostic hook: hand the context a device buffer [nb][8] of uint64 that builds compiled with
  * -DSOS_PROFILE_PHASES fill with per-phase cycle sums of the solver kernel (0 order-1 fill, 1 formal solution,
  * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.

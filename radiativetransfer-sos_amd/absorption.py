@@ -259,11 +259,11 @@ def coeff_abs_ckd(nabs, ki, tab_pres, tab_temp, tab_conc, prs, tmp, conc):
     return float(xk), prs, tmp, conc
 
 
-def prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil=None, root=None):
-    """SOS_PREPA_ABSPROFILE.  Returns dict(nu, lamb1, altabs[50] descending, userprofil[50][13], ro[8][50] molecules/cm2
-    per layer (J = 1 lowest layer; entry 50 keeps the level value, as in the reference), gas tables of the interval
-    LAMB1: nexp[8], kdis_ai[5][8], ki[8] (per gas [5][NP][NT] / H2O [5][NC][NP][NT]), tab_pres, tab_temp, tab_conc)."""
-    root = root or fic_root()
+@functools.lru_cache(maxsize=8)
+def _atmosphere(psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil, root, _stamp):
+    """The wavelength-independent half of SOS_PREPA_ABSPROFILE (SOS_PREPA_ABSPROFILE.F:441-553): profile table, layer amounts
+    of the eight gases, scaling to the user's H2O / O3 / CO2 / CH4 amounts.  Cached: a spectrum of calls shares it (the arrays
+    are read-only from here on).  _stamp: (size, mtime) of the user profile file, so that an edited file is re-read."""
     user = np.zeros((NLEVEL, NBCOL))
     if absprofil == 0:
         user = read_user_profile(ficabsprofil)
@@ -305,6 +305,31 @@ def prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprof
     if ch4 >= 0.:
         ro[5] = ro[5] * ch4 / ch4_def
         user[:, 8] = user[:, 8] * ch4 / ch4_def
+    for a in (user, ro, altabs):
+        a.setflags(write=False)
+    return user, ro, altabs
+
+
+def prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil=None, root=None):
+    """SOS_PREPA_ABSPROFILE.  Returns dict(nu, lamb1, altabs[50] descending, userprofil[50][13], ro[8][50] molecules/cm2
+    per layer (J = 1 lowest layer; entry 50 keeps the level value, as in the reference), gas tables of the interval
+    LAMB1: nexp[8], kdis_ai[5][8], ki[8] (per gas [5][NP][NT] / H2O [5][NC][NP][NT]), tab_pres, tab_temp, tab_conc)."""
+    root = root or fic_root()
+    stamp = None
+    if absprofil == 0:
+        try:
+            st = os.stat(ficabsprofil)
+            stamp = (st.st_size, st.st_mtime_ns)
+        except OSError:
+            stamp = None
+    else:
+        try:
+            st = os.stat(os.path.join(root, "SO2-NO2"))
+            stamp = (st.st_size, st.st_mtime_ns)
+        except OSError:
+            stamp = None
+    user, ro, altabs = _atmosphere(float(psurf), float(h2o), float(o3), float(co2), float(ch4), int(absprofil),
+                                   ficabsprofil if absprofil == 0 else None, root, stamp)
     nu = _F(1.0E+4) / wa
     if nu > CKD_NUMAX or nu < CKD_NUMIN:
         raise AbsorptionError("The simulation wavelength is not included in the spectral range of CKD data")
@@ -365,6 +390,11 @@ def coeff_abs_ckd_rows(nabs, ki, tab_pres, tab_temp, tab_conc, prs, tmp, conc):
     ca = conc[act]
     if tab_conc is not None:
         ca = np.minimum(np.maximum(ca, tab_conc[0]), tab_conc[-1])
+    if not ki.any():
+        # an all-zero table (NMAXAI = 0: the gas does not absorb in this interval -- most gases, most intervals): every
+        # interpolation of zeros is zero; only the clamped state is carried on
+        prs[act], conc[act] = pa, ca
+        return xk, prs, tmp, conc
     ip = _bracket(tab_pres, pa)
     if nabs == 1:
         ic = _bracket(tab_conc, ca)

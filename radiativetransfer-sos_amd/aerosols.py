@@ -5,7 +5,8 @@ functions, 5 user mixture of log-normal / Junge modes.
     mie_angles        <- SOS_ANGLES for the Mie angle set  src/SOS_ANGLES.F:380-466 (Gauss nodes, D21.14 text values)
     alpha_grid        <- the size-parameter loop of SOS_MIE  src/SOS_MIE.F:434-443, 707-708
     mie_records       <- SOS_MIE + SOS_FPHASE_MIE on the GPU (csrc/mie.hip, C ABI sosgpu_mie), no MIE cache file
-    granu             <- SOS_GRANU  src/SOS_AEROSOLS.F:4392-4820  size-distribution integral of the Mie records
+    size_integral     <- SOS_MIE + SOS_GRANU  src/SOS_AEROSOLS.F:4392-4820  size-distribution integral of the Mie records, on
+                         the GPU as well (sosgpu_granu; the numpy restatement of SOS_GRANU is tests/aerosol_loops.py)
     decompo_legendre  <- SOS_DECOMPO_LEGENDRE  src/SOS_AEROSOLS.F:3924-4390  truncation + Legendre expansions
     init_param_wmo    <- SOS_INIT_PARAMWMO  src/SOS_AEROSOLS.F:3334   (component table $SOS_ABS_ROOT/fic/Data_WMO_*)
     init_param_sf     <- SOS_INIT_PARAMSF   src/SOS_AEROSOLS.F:3557   (Data_SF_*, IRefrac_* tables)
@@ -13,10 +14,12 @@ functions, 5 user mixture of log-normal / Junge modes.
                          3: :1710-2125; 4: :2143-2280; 5: :2289-2770; closing :2771-2890)
 
 REAL*4 variables and literals of the Fortran are kept REAL*4 (`np.float32`) where they decide a value."""
+import collections
 import ctypes as C
 import functools
 import math
 import os
+import threading
 
 import numpy as np
 
@@ -77,71 +80,115 @@ def alpha_grid(alphao, alphaf):
     return np.array(out)
 
 
-def mie_records(xmu, rn, in_, alphao, alphaf, device=0):
-    """The records of the reference's MIE file for (rn, in_) on the grid alpha_grid(alphao, alphaf):
-    dict(alpha, qext, qsca float32 [na]; g float64 [na]; imie, qmie, umie float32 [na][2N+1])."""
+# Device-resident Mie records of the last few (refractive index, angle set, size-parameter range) combinations: what the
+# reference keeps as MIE cache files named after exactly these quantities (SOS_NOM_FICMIE, SOS_AEROSOLS.F:3128 --
+# "MIE1.450-0.00300-0.0001-00100.00-MU12") and re-reads for every wavelength that shares them.  2 MB each at 40 Mie angles.
+_MIE_CACHE = collections.OrderedDict()
+_MIE_LOCK = threading.Lock()
+_MIE_CACHE_MAX = 12
+
+
+def _mie_device_records(xmu, rn, in_, alphao, alphaf, device=0):
+    """(rec float32 [na][4 + 3 W], g float64 [na]) device tensors of sosgpu_mie for the grid alpha_grid(alphao, alphaf)."""
     import torch
     if not torch.cuda.is_available():
-        raise RuntimeError("mie_records needs a GPU (gfx950); there is no CPU fallback in the product path")
-    al = alpha_grid(alphao, alphaf)
+        raise RuntimeError("Mie theory needs a GPU (gfx950); there is no CPU fallback in the product path")
     xmu = np.ascontiguousarray(xmu, dtype=np.float64)
+    key = (xmu.tobytes(), float(rn), float(in_), float(alphao), float(alphaf), int(device))
+    with _MIE_LOCK:
+        hit = _MIE_CACHE.get(key)
+        if hit is not None:
+            _MIE_CACHE.move_to_end(key)
+            return hit
+    al = alpha_grid(alphao, alphaf)
     w = len(xmu)
-    nbmu = (w - 1) // 2
     dev = torch.device("cuda", device)
     rec = torch.zeros((len(al), 4 + 3 * w), dtype=torch.float32, device=dev)
     g = torch.zeros(len(al), dtype=torch.float64, device=dev)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    rc = capi.lib().sosgpu_mie(device, nbmu, xmu.ctypes.data_as(C.c_void_p), float(rn), float(in_), len(al),
+    rc = capi.lib().sosgpu_mie(device, (w - 1) // 2, xmu.ctypes.data_as(C.c_void_p), float(rn), float(in_), len(al),
                                al.ctypes.data_as(C.c_void_p), C.c_void_p(rec.data_ptr()), C.c_void_p(g.data_ptr()), st)
     if rc == -3:
         raise AerosolError("size parameter up to %g: more Mie coefficients than the device kernel holds" % alphaf)
-    capi.check(rc, "sosgpu_mie")
+    capi.check(rc, "sosgpu_mie")               # (synchronous: the records are complete, usable from any stream)
+    with _MIE_LOCK:
+        _MIE_CACHE[key] = (rec, g)
+        while len(_MIE_CACHE) > _MIE_CACHE_MAX:
+            _MIE_CACHE.popitem(last=False)
+    return rec, g
+
+
+def mie_records(xmu, rn, in_, alphao, alphaf, device=0):
+    """The records of the reference's MIE file for (rn, in_) on the grid alpha_grid(alphao, alphaf), on the host (parity
+    accessor): dict(alpha, qext, qsca float32 [na]; g float64 [na]; imie, qmie, umie float32 [na][2N+1])."""
+    rec, g = _mie_device_records(xmu, rn, in_, alphao, alphaf, device)
+    w = len(xmu)
     r = rec.cpu().numpy()
     return dict(alpha=r[:, 0].copy(), qext=r[:, 1].copy(), qsca=r[:, 2].copy(), g=g.cpu().numpy(), imie=r[:, 4:4 + w].copy(),
                 qmie=r[:, 4 + w:4 + 2 * w].copy(), umie=r[:, 4 + 2 * w:4 + 3 * w].copy(), alphaf=float(alphaf))
 
 
-def granu(rec, igranu, v1, v2, v3, wa):
-    """SOS_GRANU: integral of the Mie records over the size distribution (igranu 1: log-normal, modal radius v1, ln-std v2;
-    2: Junge, r0 = v1, slope v2, rmax = v3).  Returns kmat1, kmat2 (per particle), somme_nr, p11, p12, p33 [2N+1]."""
-    alpha = rec["alpha"]                               # REAL*4 in the file
-    a64 = alpha.astype(np.float64)
-    r = a64 * wa / 2. / math.pi
-    pas = np.full(len(alpha), np.float32(0.0001), dtype=np.float32)
-    for lim, st in ((0.10, 0.001), (1.00, 0.01), (10., 0.05), (30., 0.10), (100., 1.00)):
-        pas[alpha > np.float32(lim)] = np.float32(st)
-    pas_prev = np.concatenate([[np.float32(0.0001)], pas[:-1]]).astype(np.float64)
-    stop = a64 >= (rec["alphaf"] - pas_prev)
-    nuse = int(np.argmax(stop)) if stop.any() else len(alpha)
-    if igranu == 1:
-        b = np.log(r / v1) / v2
-        nr = np.exp(-b * b / 2.) / (r * v2 * math.sqrt(2 * math.pi))
-    elif igranu == 2:
-        over = r > v3
-        if over[:nuse].any():
-            nuse = int(np.argmax(over))
-        nr = np.where(r <= v1, v1 ** (-v2), r ** (-v2))
-    else:
+def size_integral(xmu, rn, in_, alphaf, igranu, v1, v2, v3, wa, device=0):
+    """SOS_MIE + SOS_GRANU for one aerosol mode, both on the GPU: Mie records on the grid alpha_grid(MIE_ALPHAMIN, alphaf)
+    (sosgpu_mie; kept on the device and shared by the wavelengths of a spectrum, like the reference's MIE files) integrated
+    over the size distribution in record order (sosgpu_granu; igranu 1: log-normal, modal radius v1, ln-std v2; 2: Junge,
+    r0 = v1, slope v2, rmax = v3).  Returns kmat1, kmat2 (per particle), somme_nr, p11, p12, p33 [2N+1]."""
+    import torch
+    if igranu not in (1, 2):
         raise AerosolError("unknown size distribution %d" % igranu)
-    sl = slice(0, nuse)
-    # the record loop of SOS_GRANU accumulates in file order (SOS_AEROSOLS.F:4600-4618): sequential sums (cumsum), not numpy's
-    # pairwise np.sum -- with the reference's own records this gives its Aerosols.txt digit for digit (tests/test_aerosols.py)
-    seq0 = lambda a: np.cumsum(a, axis=0)[-1]
-    pr = wa * pas[sl].astype(np.float64) / 2. / math.pi
-    x1 = nr[sl] * pr * math.pi * r[sl] ** 2
-    kmat1 = float(seq0(x1 * rec["qext"][sl].astype(np.float64)))
-    x1s = rec["qsca"][sl].astype(np.float64) * x1
-    kmat2 = float(seq0(x1s))
-    p11 = seq0(rec["imie"][sl].astype(np.float64) * x1s[:, None]) / kmat2
-    p12 = seq0(rec["qmie"][sl].astype(np.float64) * x1s[:, None]) / kmat2
-    p33 = seq0(rec["umie"][sl].astype(np.float64) * x1s[:, None]) / kmat2
-    somme_nr = float(seq0(nr[sl] * pr))
-    return kmat1 / somme_nr, kmat2 / somme_nr, somme_nr, p11, p12, p33
+    rec, _ = _mie_device_records(xmu, rn, in_, MIE_ALPHAMIN, alphaf, device)
+    w = len(xmu)
+    out = np.zeros(3 + 3 * w)
+    st = C.c_void_p(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
+    capi.check(capi.lib().sosgpu_granu(device, (w - 1) // 2, int(rec.shape[0]), C.c_void_p(rec.data_ptr()), int(igranu), float(v1),
+                                       float(v2), float(v3), float(wa), float(alphaf), out.ctypes.data_as(C.c_void_p), st),
+               "sosgpu_granu")
+    return float(out[0]), float(out[1]), float(out[2]), out[3:3 + w].copy(), out[3 + w:3 + 2 * w].copy(), out[3 + 2 * w:].copy()
 
 
 def _seq_sum(a):
     """Left-to-right sum along the last axis (np.cumsum accumulates sequentially, np.sum pairwise): the order of the Fortran loops."""
     return np.cumsum(a, axis=-1)[..., -1]
+
+
+@functools.lru_cache(maxsize=16)
+def _legendre_tables(xmu_bytes, os_nb):
+    """What SOS_DECOMPO_LEGENDRE computes from the angles and orders alone: Legendre polynomials PL(K) and the generalised
+    functions POL(K) at the Mie angles (SOS_AEROSOLS.F:4100-4180) and, per order I, the REAL*4 coefficient expressions CO1, CO2
+    and X2 of the alpha / zeta sums (:4330-4375, as in SOS_MAT_FRESNEL) with the indices they multiply.  Cached per angle set."""
+    xmu = np.frombuffer(xmu_bytes, dtype=np.float64)
+    w = len(xmu)
+    n = (w - 1) // 2
+    sel = np.array([j for j in range(w) if j != n])                 # J = -N..N without 0, ascending
+    xr = xmu[sel]
+    # Legendre polynomials P_k(xr): PL(K+1) = ((2K+1) X PL(K) - K PL(K-1)) / (K+1)
+    pl = np.zeros((os_nb + 2, len(sel)))
+    pl[0] = 1.
+    plm = np.zeros(len(sel))
+    for k in range(os_nb + 1):
+        pl[k + 1] = ((2 * k + 1.) * xr * pl[k] - k * (pl[k - 1] if k else plm)) / (k + 1.)
+    # generalised functions POL(K), K >= 2
+    pol = np.zeros((os_nb + 2, len(sel)))
+    pol[2] = 3. * (1. - xr ** 2) / 2. / math.sqrt(6.0)
+    for k in range(2, os_nb + 1):
+        d = (2. * k + 1.) / math.sqrt(1. * (k + 3.) * (k - 1.))
+        e = math.sqrt(1. * (k + 2.) * (k - 2.)) / (2. * k + 1.)
+        pol[k + 1] = d * (xr * pol[k] - e * pol[k - 1])
+    f = np.float32
+    coefs = []
+    for i in range(2, os_nb + 1):               # CO1, CO2, X2 are REAL*4 expressions
+        co1 = float(f(4) * (f(2 * i) + f(1.)) / f(i) / (f(i) - f(1.)) / (f(i) + f(1.)) / (f(i) + f(2.)))
+        co2 = float(f(i) * (f(i) - f(1.)) / ((f(i) + f(1.)) * (f(i) + f(2.))))
+        nn, mm = int(i * .5), int((i - 1) * .5)
+        fi1 = (f(i) - f(1.)) * (f(i) - f(1.))
+        jn = np.arange(1, nn + 1)
+        x2n = (fi1 - f(3.) * ((2 * jn).astype(np.float32) - f(1.)) * (i - jn).astype(np.float32)).astype(np.float64)
+        jm = np.arange(0, mm + 1)
+        x2m = (fi1 - f(3.) * jm.astype(np.float32) * ((2 * i - 2 * jm).astype(np.float32) - f(1.))).astype(np.float64)
+        coefs.append((co1, co2, i - 2 * jn, x2n, i - 2 * jm - 1, x2m))
+    for a in (sel, xr, pl, pol):
+        a.setflags(write=False)
+    return sel, xr, pl, pol, tuple(coefs)
 
 
 def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
@@ -155,14 +202,7 @@ def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
     J = lambda j: j + n
     ttt = p11_in.copy()
     kk = np.arange(os_nb + 1)
-    sel = np.array([j for j in range(w) if j != n])                 # J = -N..N without 0, ascending
-    xr = xmu[sel]
-    # Legendre polynomials P_k(xr): PL(K+1) = ((2K+1) X PL(K) - K PL(K-1)) / (K+1)
-    pl = np.zeros((os_nb + 2, len(sel)))
-    pl[0] = 1.
-    plm = np.zeros(len(sel))
-    for k in range(os_nb + 1):
-        pl[k + 1] = ((2 * k + 1.) * xr * pl[k] - k * (pl[k - 1] if k else plm)) / (k + 1.)
+    sel, xr, pl, pol, coefs = _legendre_tables(np.ascontiguousarray(xmu, dtype=np.float64).tobytes(), os_nb)
     while True:
         p11 = ttt.copy()
         if itronc:
@@ -182,13 +222,6 @@ def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
             itronc = 0                    # truncation too small to matter: start again without it (SOS_AEROSOLS.F:4195-4214)
             continue
         break
-    # generalised functions POL(K), K >= 2
-    pol = np.zeros((os_nb + 2, len(sel)))
-    pol[2] = 3. * (1. - xr ** 2) / 2. / math.sqrt(6.0)
-    for k in range(2, os_nb + 1):
-        d = (2. * k + 1.) / math.sqrt(1. * (k + 3.) * (k - 1.))
-        e = math.sqrt(1. * (k + 2.) * (k - 2.)) / (2. * k + 1.)
-        pol[k + 1] = d * (xr * pol[k] - e * pol[k - 1])
     xxx = xhr[sel] * p12[sel] * p11[sel] / ttt[sel]
     xb = xhr[sel] * p22[sel] * (p11[sel] / ttt[sel])
     xx = xhr[sel] * p33[sel] * p11[sel] / ttt[sel]
@@ -200,24 +233,15 @@ def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
     delta33 = delta33 * (2. * kk + 1.) * .5
     gamma12 = gamma12 * (2. * kk + 1.) * .5
     alp, zeta = np.zeros(os_nb + 1), np.zeros(os_nb + 1)
-    f = np.float32
-    for i in range(2, os_nb + 1):               # CO1, CO2, X2 are REAL*4 expressions (as in SOS_MAT_FRESNEL)
-        co1 = float(f(4) * (f(2 * i) + f(1.)) / f(i) / (f(i) - f(1.)) / (f(i) + f(1.)) / (f(i) + f(2.)))
-        co2 = float(f(i) * (f(i) - f(1.)) / ((f(i) + f(1.)) * (f(i) + f(2.))))
-        co3 = co2 * delta33[i]
-        co2 = co2 * beta22[i]
-        nn, mm = int(i * .5), int((i - 1) * .5)
-        fi1 = (f(i) - f(1.)) * (f(i) - f(1.))
-        s1 = s2 = s3 = s4 = 0.
-        if nn >= 1:
-            jn = np.arange(1, nn + 1)
-            x2 = (fi1 - f(3.) * ((2 * jn).astype(np.float32) - f(1.)) * (i - jn).astype(np.float32)).astype(np.float64)
-            s1 = float(_seq_sum(x2 * beta22[i - 2 * jn]))
-            s2 = float(_seq_sum(x2 * delta33[i - 2 * jn]))
-        jm = np.arange(0, mm + 1)
-        x2 = (fi1 - f(3.) * jm.astype(np.float32) * ((2 * i - 2 * jm).astype(np.float32) - f(1.))).astype(np.float64)
-        s3 = float(_seq_sum(x2 * beta22[i - 2 * jm - 1]))
-        s4 = float(_seq_sum(x2 * delta33[i - 2 * jm - 1]))
+    for i, (co1, co2r, jn_idx, x2n, jm_idx, x2m) in enumerate(coefs, start=2):
+        co3 = co2r * delta33[i]
+        co2 = co2r * beta22[i]
+        s1 = s2 = 0.
+        if len(jn_idx):
+            s1 = float(_seq_sum(x2n * beta22[jn_idx]))
+            s2 = float(_seq_sum(x2n * delta33[jn_idx]))
+        s3 = float(_seq_sum(x2m * beta22[jm_idx]))
+        s4 = float(_seq_sum(x2m * delta33[jm_idx]))
         zeta[i] = co3 - co1 * (s2 - s3)
         alp[i] = co2 - co1 * (s1 - s4)
     z1 = beta11[0]
@@ -243,8 +267,7 @@ def _round_index(rn, in_):
 
 
 def _lnd_component(xmu, rn, in_, rmodal, var, alphaf, wa, device):
-    rec = mie_records(xmu, rn, in_, MIE_ALPHAMIN, alphaf, device)
-    k1, k2, _, a11, a12, a33 = granu(rec, 1, rmodal, var, -999.0, wa)
+    k1, k2, _, a11, a12, a33 = size_integral(xmu, rn, in_, alphaf, 1, rmodal, var, -999.0, wa, device)
     return k1, k2, a11, a12, a33
 
 
@@ -502,8 +525,7 @@ def _user_mixture(p, wa, xmu, device):
         return _alphaf(rmax, WAMIN)
     coef, tot = [], 0.
     for m, tau in zip(modes, aot):
-        rec = mie_records(xmu, m["rn_waref"], m["in_waref"], MIE_ALPHAMIN, alphaf_of(m), device)
-        k1 = granu(rec, m["igranu"], m["v1"], m["v2"], m["v3"], waref)[0]
+        k1 = size_integral(xmu, m["rn_waref"], m["in_waref"], alphaf_of(m), m["igranu"], m["v1"], m["v2"], m["v3"], waref, device)[0]
         coef.append(tau / k1)
         tot = tot + coef[-1]
     coef = [c / tot for c in coef]
@@ -512,8 +534,7 @@ def _user_mixture(p, wa, xmu, device):
     p11, p12, p33 = np.zeros(w), np.zeros(w), np.zeros(w)
     for m, c in zip(modes, coef):
         rn, in_ = (m["rn_waref"], m["in_waref"]) if wa == waref else (m["rn_wa"], m["in_wa"])
-        rec = mie_records(xmu, rn, in_, MIE_ALPHAMIN, alphaf_of(m), device)
-        k1, k2, _, a11, a12, a33 = granu(rec, m["igranu"], m["v1"], m["v2"], m["v3"], wa)
+        k1, k2, _, a11, a12, a33 = size_integral(xmu, rn, in_, alphaf_of(m), m["igranu"], m["v1"], m["v2"], m["v3"], wa, device)
         kmat1 = kmat1 + c * k1
         kmat2 = kmat2 + c * k2
         p11 = p11 + a11 * c * k2
@@ -548,8 +569,7 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
         else:
             raise AerosolError("-AER.MMD.SDtype must be 1 (LND) or 2 (Junge)")
         af = _alphaf(rmax, WAMIN)                     # mono-modal model: grid sized for the shortest wavelength (:1158)
-        rec = mie_records(xmu, rn, in_, MIE_ALPHAMIN, af, device)
-        kmat1, kmat2, _, p11, p12, p33 = granu(rec, igranu, v1, v2, v3, wa)
+        kmat1, kmat2, _, p11, p12, p33 = size_integral(xmu, rn, in_, af, igranu, v1, v2, v3, wa, device)
     elif imod == 3:
         modes = []
         for m in ("cm", "fm"):
@@ -563,8 +583,8 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
             waref, kref = p["waref_aot"], []
             for m, md in zip(("cm", "fm"), modes):
                 rnr, inr = _round_index(p["bmd_%s_mrwaref" % m], p["bmd_%s_miwaref" % m])
-                rec = mie_records(xmu, rnr, inr, MIE_ALPHAMIN, _alphaf(_rmax_lnd(md["r"], md["v"]), waref), device)
-                kref.append(granu(rec, 1, md["r"], md["v"], -999.0, waref)[0])
+                kref.append(size_integral(xmu, rnr, inr, _alphaf(_rmax_lnd(md["r"], md["v"]), waref), 1, md["r"], md["v"], -999.0,
+                                          waref, device)[0])
             rt, ta_ref = p["rtauct_waref"], p["aot_ref"]
             cvi = [(rt * ta_ref) / kref[0], ((1. - rt) * ta_ref) / kref[1]]
         else:
@@ -577,8 +597,8 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
         for c, md in zip(cvi, modes):
             if c == 0.:
                 continue
-            rec = mie_records(xmu, md["rn"], md["in_"], MIE_ALPHAMIN, _alphaf(_rmax_lnd(md["r"], md["v"]), wa), device)
-            k1, k2, _, a11, a12, a33 = granu(rec, 1, md["r"], md["v"], -999.0, wa)
+            k1, k2, _, a11, a12, a33 = size_integral(xmu, md["rn"], md["in_"], _alphaf(_rmax_lnd(md["r"], md["v"]), wa), 1, md["r"],
+                                                     md["v"], -999.0, wa, device)
             kmat1 = kmat1 + c * k1
             kmat2 = kmat2 + c * k2
             p11 = p11 + c * a11 * k2

@@ -1255,6 +1255,28 @@ extern "C" int sosgpu_mie(int device, int nbmu, const double *xmu, double rn, do
     return err ? SOSGPU_E_UNSUPPORTED : SOSGPU_OK;
 }
 
+extern "C" int sosgpu_granu(int device, int nbmu, int nalpha, const float *d_rec, int igranu, double v1, double v2, double v3,
+                            double wa, double alphaf, double *out, void *stream)
+{
+    if (nbmu < 1 || nbmu > 100 || nalpha < 1 || !d_rec || igranu < 1 || igranu > 2 || !out || !(wa > 0.)) return SOSGPU_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nout = (size_t)3 + 3 * (2 * nbmu + 1), nwork = (size_t)3 * nalpha + 1;
+    TmpBuf tb(device, (nout + nwork) * sizeof(double));
+    if (!tb.p) return SOSGPU_E_HIP;
+    double *d_out = (double *)tb.p, *d_work = d_out + nout;
+    launch_granu(nalpha, nbmu, d_rec, igranu, v1, v2, v3, wa, alphaf, d_work, d_out, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else (void)hipStreamSynchronize(st);
+    HIPCHK(e);
+    return SOSGPU_OK;
+}
+
 // Diagnostic: per-bin phase cycle counters [nb][8] (filled only by builds with -DSOS_PROFILE_PHASES).
 extern "C" int sosgpu_debug_phase_buffer(sosgpu_ctx *cx, unsigned long long *d_phase)
 {

@@ -64,5 +64,8 @@ void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const d
 // Mie records of a size-parameter grid (mie.hip): rec[nalpha][4 + 3 (2 nbmu + 1)] floats, g[nalpha]; returns 0, -2 (HIP) or -3
 // (alpha_max beyond the LDS-resident coefficient arrays)
 size_t mie_scratch_doubles(double alpha_max, int count);
+// SOS_GRANU on the device records: d_work[3 na + 1], d_out[3 + 3 (2 nbmu + 1)] (mie.hip)
+void launch_granu(int na, int nbmu, const float *d_rec, int igranu, double v1, double v2, double v3, double wa, double alphaf,
+                  double *d_work, double *d_out, hipStream_t st);
 int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, const double *d_alphas, int n_lds, double alpha_lds,
                double alpha_max, double *d_scratch, float *d_rec, double *d_g, int32_t *d_err, hipStream_t st);

@@ -191,3 +191,111 @@ int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, 
     }
     return 0;
 }
+
+// SOS_GRANU (src/SOS_AEROSOLS.F:4392-4820) on the device: the integral of the Mie records over the size distribution, so that
+// the records (2 MB per wavelength at 40 Mie angles) never travel to the host.  The reference reads the MIE file record by
+// record and ACCUMULATES in file order (:4600-4618); here pass 1 forms the per-record weights in parallel and pass 2 adds them
+// up in record order, one thread per output (3 W phase-function entries + the three scalars), so the sums are the Fortran
+// loop's sums term for term.  igranu 1: log-normal (v1 modal radius, v2 ln-std); 2: Junge (v1 = r0, v2 slope, v3 = rmax).
+//   out[0..2] = KMAT1 / SOMME_NR, KMAT2 / SOMME_NR, SOMME_NR;  out[3 + c W + j] = P11 | P12 | P33 (normalised by KMAT2)
+// work[3 na + 1]: x1 qext | qsca x1 | nr pr, and the number of records used (the loop's exit, :4520 / :4585).
+__global__ void k_granu(int na, int nbmu, const float *__restrict__ rec, int igranu, double v1, double v2, double v3, double wa,
+                        double alphaf, double *__restrict__ work, double *__restrict__ out)
+{
+    __shared__ int s_nuse;
+    const int t = threadIdx.x, W = 2 * nbmu + 1, RS = 4 + 3 * W;
+    const double pi = 3.141592653589793;
+    if (t == 0) s_nuse = na;
+    __syncthreads();
+    auto step_of = [](float a) {           // the REAL*4 step ladder of SOS_GRANU (:4523-4527), same literals as SOS_MIE's
+        float pas = 0.0001f;
+        if (a > 0.10f) pas = 0.001f;
+        if (a > 1.00f) pas = 0.01f;
+        if (a > 10.f) pas = 0.05f;
+        if (a > 30.f) pas = 0.10f;
+        if (a > 100.f) pas = 1.00f;
+        return pas;
+    };
+    double *wq = work, *ws = work + na, *wn = work + 2 * (size_t)na;
+    for (int i = t; i < na; i += blockDim.x) {
+        const float af = rec[(size_t)i * RS];
+        const double a64 = (double)af;
+        const double r = a64 * wa / 2. / pi;
+        const float pas = step_of(af);
+        const double pas_prev = (double)(i ? step_of(rec[(size_t)(i - 1) * RS]) : 0.0001f);
+        bool stop = a64 >= (alphaf - pas_prev);                                      // IF (ALPHA.GE.(ALPHAF-PAS)) GOTO 40
+        double nr;
+        if (igranu == 1) {
+            const double b = log(r / v1) / v2;
+            nr = exp(-b * b / 2.) / (r * v2 * sqrt(2 * pi));
+        } else {
+            if (r > v3) stop = true;                                                 // IF (R.GT.RMAX) GOTO 40
+            nr = (r <= v1) ? pow(v1, -v2) : pow(r, -v2);
+        }
+        if (stop) atomicMin(&s_nuse, i);
+        const double pr = wa * (double)pas / 2. / pi;
+        const double x1 = nr * pr * pi * (r * r);
+        wq[i] = x1 * (double)rec[(size_t)i * RS + 1];
+        ws[i] = (double)rec[(size_t)i * RS + 2] * x1;
+        wn[i] = nr * pr;
+    }
+    __syncthreads();
+    const int nuse = s_nuse;
+    __shared__ double s_k[3];
+    // pass 2: tiles of GT records go through LDS (coalesced loads); thread o then adds its column of the tile in record order.
+    // One thread per output: 3 W phase-function sums + the three scalar sums (o = 0..2 read the work arrays).
+    constexpr int GT = 32;
+    extern __shared__ double lds[];
+    double *t_ws = lds;                                     // [GT] qsca x1 of the tile
+    double *t_sc = t_ws + GT;                               // [GT][2] x1 qext | nr pr
+    float *t_rec = reinterpret_cast<float *>(t_sc + 2 * GT);   // [GT][3 W] phase-function entries
+    const int NO = 3 * W + 3;
+    double acc[2] = {0., 0.};                               // outputs t and t + blockDim.x (3 W + 3 <= 2 blockDim.x)
+    for (int i0 = 0; i0 < nuse; i0 += GT) {
+        const int cnt = min(GT, nuse - i0);
+        __syncthreads();
+        for (int e = t; e < cnt * 3 * W; e += blockDim.x) {
+            const int i = e / (3 * W), c = e - i * 3 * W;
+            t_rec[i * 3 * W + c] = rec[(size_t)(i0 + i) * RS + 4 + c];
+        }
+        for (int e = t; e < cnt; e += blockDim.x) { t_ws[e] = ws[i0 + e]; t_sc[2 * e] = wq[i0 + e]; t_sc[2 * e + 1] = wn[i0 + e]; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int o = t + u * blockDim.x;
+            if (o >= NO) continue;
+            double a = acc[u];
+            if (o == 0) for (int i = 0; i < cnt; i++) a = a + t_sc[2 * i];
+            else if (o == 1) for (int i = 0; i < cnt; i++) a = a + t_ws[i];
+            else if (o == 2) for (int i = 0; i < cnt; i++) a = a + t_sc[2 * i + 1];
+            else {
+                const float *col = t_rec + (o - 3);
+                for (int i = 0; i < cnt; i++) a = a + (double)col[i * 3 * W] * t_ws[i];
+            }
+            acc[u] = a;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int o = t + u * blockDim.x;
+        if (o < 3) s_k[o] = acc[u];
+        else if (o < NO) out[o] = acc[u];                   // normalised below
+    }
+    __syncthreads();
+    const double kmat1 = s_k[0], kmat2 = s_k[1], somme = s_k[2];
+    for (int o = t; o < 3 * W + 3; o += blockDim.x) {
+        if (o == 0) out[0] = kmat1 / somme;
+        else if (o == 1) out[1] = kmat2 / somme;
+        else if (o == 2) out[2] = somme;
+        else out[o] = out[o] / kmat2;
+    }
+    if (t == 0) work[3 * (size_t)na] = (double)nuse;
+}
+
+void launch_granu(int na, int nbmu, const float *d_rec, int igranu, double v1, double v2, double v3, double wa, double alphaf,
+                  double *d_work, double *d_out, hipStream_t st)
+{
+    const int W = 2 * nbmu + 1;                              // nbmu <= 100: 3 W + 3 = 606 outputs, two per thread of 320
+    const size_t lds = (size_t)(32 + 64) * sizeof(double) + (size_t)32 * 3 * W * sizeof(float);
+    k_granu<<<1, 320, lds, st>>>(na, nbmu, d_rec, igranu, v1, v2, v3, wa, alphaf, d_work, d_out);
+}

@@ -758,6 +758,32 @@ def trphi_tables(ctx, rec, nf, tau, tauout, itrphi, phios, pas_phi, igli, wind, 
     return _trphi_pack(ctx.n, ctx.mu, out, rows, phi_fin)
 
 
+# SOS_AEROSOLS at the REFERENCE wavelength (the first of the two runs SOS_PROC makes when -SOS_Main.Wa differs from -AER.Waref,
+# SOS_PROC.F:2893): it depends on the aerosol keywords only, not on the simulation wavelength, so the calls of a spectrum share
+# it (the reference recomputes it -- and re-reads its MIE cache file -- in every call).  Keyed by every -AER.* keyword.
+_AER_REF_CACHE = collections.OrderedDict()
+_AER_REF_LOCK = threading.Lock()
+
+
+def _aerosols_at_waref(p, nb_mie, os_nb, device):
+    from . import aerosols as _aer
+    key = tuple((k, p[k]) for _, k, _ in PARAMS if k.startswith(("imod_aer", "rn_", "in_", "igranu", "lnd_", "jd_", "imodele_", "c_wmo_",
+                                                                "rh", "mode_param", "user_cv", "rtauct", "bmd_", "ficextdata",
+                                                                "ficmixture", "itronc", "waref_aot", "aot_ref"))) + (
+        nb_mie, os_nb, device, os.environ.get("SOS_ABS_ROOT", ""))
+    with _AER_REF_LOCK:
+        hit = _AER_REF_CACHE.get(key)
+        if hit is not None:
+            _AER_REF_CACHE.move_to_end(key)
+            return dict(hit)
+    out = _aer.aerosols(p, p["waref_aot"], p["aot_ref"], nb_mie, os_nb, at_waref=True, device=device)
+    with _AER_REF_LOCK:
+        _AER_REF_CACHE[key] = dict(out)
+        while len(_AER_REF_CACHE) > 16:
+            _AER_REF_CACHE.popitem(last=False)
+    return out
+
+
 def _prepare(kw, aer_phase=None, device=0, shard_bins=True):
     """Everything of one SOS_PROC call up to the CKD bin loop (SOS_PROC.F:1310-3458): parameter checks, SOS_ANGLES,
     SOS_AEROSOLS, SOS_SURFACE, SOS_PREPA_ABSPROFILE, SOS_PREPA_OS, and the profiles of every bin of the band on the device
@@ -829,7 +855,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True):
         if p["waref_aot"] == _D:
             raise SosProcError("-AER.Waref must be defined")
         try:
-            aer_phase = _aer.aerosols(p, p["waref_aot"], p["aot_ref"], nb_mie, os_nb, at_waref=True, device=device)
+            aer_phase = _aerosols_at_waref(p, nb_mie, os_nb, device)
             ta_model = float(p["aot_ref"])
             if p["wa_simu"] != p["waref_aot"]:
                 k_ref = aer_phase["kmat1"]
@@ -1110,6 +1136,47 @@ def _any_rank_failed(failed, device):
     t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=torch.device("cuda", device) if on_gpu else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return bool(int(t.item()))
+
+
+def sos_proc_many(kwargs_list, n_workers=8, device=0):
+    """A spectrum of independent sos_proc calls (one per wavelength: the reference runs them one after the other,
+    binding/run_sos.py:640) issued from `n_workers` host threads, each on its own HIP stream.  One call spends most of its
+    wall clock waiting for the few bins of its band (a bin is a serial chain of scattering orders: milliseconds on a small
+    fraction of the chip); here the waits of one wavelength overlap the host work and the kernels of the others.  Every call
+    is the unchanged sos_proc -- results are identical to the sequential loop.  Give each call its own `-SOS_Main.ResRoot`
+    when result files are wanted (the file names inside are fixed, as in the reference).  Export GPU_MAX_HW_QUEUES=16 before
+    the first GPU call (solver.solve_many).  Returns the list of 23-tuples in order; the first failing call's exception is
+    raised after all calls have ended."""
+    import concurrent.futures
+    import torch
+    from . import capi
+    capi.lib()                                             # loaded once, before the threads
+    if not kwargs_list:
+        return []
+    if _dist_rank_world()[1] > 1:
+        raise SosProcError("sos_proc_many: with torch.distributed initialised every sos_proc call is a collective over the "
+                           "ranks (the band's bins are sharded) -- issue the calls one after the other")
+    dev = torch.device("cuda", device)
+    nw = max(1, min(int(n_workers), len(kwargs_list)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]
+    import threading
+    slot = threading.local()
+    free = list(range(nw))
+    lock = threading.Lock()
+
+    def one(kw):
+        if not hasattr(slot, "i"):
+            with lock:
+                slot.i = free.pop()
+        with torch.cuda.device(dev), torch.cuda.stream(streams[slot.i]):
+            out = sos_proc(device=device, **kw)
+            streams[slot.i].synchronize()
+        return out
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=nw) as ex:
+        futs = [ex.submit(one, kw) for kw in kwargs_list]
+        concurrent.futures.wait(futs)
+    return [f.result() for f in futs]
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -23,7 +23,10 @@ class SosBinError(RuntimeError):
 def _dev_f64(x, device):
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.float64).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(device)
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if not a.flags.writeable:                      # (cached read-only tables: torch wants a writable buffer to wrap)
+        a = a.copy()
+    return torch.from_numpy(a).to(device)
 
 
 def _dev_i32(x, device):

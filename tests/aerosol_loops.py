@@ -1,5 +1,7 @@
-"""The statement-for-statement loop form of SOS_DECOMPO_LEGENDRE (src/SOS_AEROSOLS.F:3924-4390) -- test infrastructure: the
-product's vectorised aerosols.decompo_legendre is checked against it bit for bit (tests/test_aerosols.py)."""
+"""Host restatements used as checkers -- test infrastructure: the statement-for-statement loop form of SOS_DECOMPO_LEGENDRE
+(src/SOS_AEROSOLS.F:3924-4390), against which the product's vectorised aerosols.decompo_legendre is checked bit for bit, and
+the numpy form of SOS_GRANU (:4392-4820), which reproduces the reference's Aerosols.txt from its own MIE records and against
+which the device kernel k_granu (the product path) is checked (tests/test_aerosols.py)."""
 import importlib
 import math
 
@@ -90,3 +92,41 @@ def decompo_legendre_loops(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
     z1 = beta11[0]
     return dict(alpha=alp / z1, beta=beta11 / z1, gamma=gamma12 / z1, zeta=zeta / z1, beta22=beta22 / z1, delta33=delta33 / z1,
                 coef_tronca=float(coef), itronc=itronc)
+
+
+def granu_host(rec, igranu, v1, v2, v3, wa):
+    """SOS_GRANU: integral of the Mie records over the size distribution (igranu 1: log-normal, modal radius v1, ln-std v2;
+    2: Junge, r0 = v1, slope v2, rmax = v3).  Returns kmat1, kmat2 (per particle), somme_nr, p11, p12, p33 [2N+1]."""
+    alpha = rec["alpha"]                               # REAL*4 in the file
+    a64 = alpha.astype(np.float64)
+    r = a64 * wa / 2. / math.pi
+    pas = np.full(len(alpha), np.float32(0.0001), dtype=np.float32)
+    for lim, st in ((0.10, 0.001), (1.00, 0.01), (10., 0.05), (30., 0.10), (100., 1.00)):
+        pas[alpha > np.float32(lim)] = np.float32(st)
+    pas_prev = np.concatenate([[np.float32(0.0001)], pas[:-1]]).astype(np.float64)
+    stop = a64 >= (rec["alphaf"] - pas_prev)
+    nuse = int(np.argmax(stop)) if stop.any() else len(alpha)
+    if igranu == 1:
+        b = np.log(r / v1) / v2
+        nr = np.exp(-b * b / 2.) / (r * v2 * math.sqrt(2 * math.pi))
+    elif igranu == 2:
+        over = r > v3
+        if over[:nuse].any():
+            nuse = int(np.argmax(over))
+        nr = np.where(r <= v1, v1 ** (-v2), r ** (-v2))
+    else:
+        raise AerosolError("unknown size distribution %d" % igranu)
+    sl = slice(0, nuse)
+    # the record loop of SOS_GRANU accumulates in file order (SOS_AEROSOLS.F:4600-4618): sequential sums (cumsum), not numpy's
+    # pairwise np.sum -- with the reference's own records this gives its Aerosols.txt digit for digit (tests/test_aerosols.py)
+    seq0 = lambda a: np.cumsum(a, axis=0)[-1]
+    pr = wa * pas[sl].astype(np.float64) / 2. / math.pi
+    x1 = nr[sl] * pr * math.pi * r[sl] ** 2
+    kmat1 = float(seq0(x1 * rec["qext"][sl].astype(np.float64)))
+    x1s = rec["qsca"][sl].astype(np.float64) * x1
+    kmat2 = float(seq0(x1s))
+    p11 = seq0(rec["imie"][sl].astype(np.float64) * x1s[:, None]) / kmat2
+    p12 = seq0(rec["qmie"][sl].astype(np.float64) * x1s[:, None]) / kmat2
+    p33 = seq0(rec["umie"][sl].astype(np.float64) * x1s[:, None]) / kmat2
+    somme_nr = float(seq0(nr[sl] * pr))
+    return kmat1 / somme_nr, kmat2 / somme_nr, somme_nr, p11, p12, p33
