@@ -17,6 +17,11 @@ code; under a launcher (the driver's torch.distributed.run) it is one rank.  Ran
 --workload realistic (also appended to the default N = 1 line as "realistic_mix"): the same wavelength with the level
 grids SOS_PROFILE really produces (NT 117...426 from seeded gas columns, made on the device by sosgpu_profile), i.e. the
 streamed-field variant of the solver.
+--workload hyperspectral (also appended to the default N = 1 line as "hyperspectral"): BASELINE config 5 through the drop-in --
+run_sos.sos_spectrum over the 2496 spectral intervals of 2500-27500 cm-1 (synthetic CKD tables with the reference's own
+number of exponential terms per gas and interval, scripts/synth_ckd.py; 5732 bins), wavelengths dealt to the ranks.
+--scaling strong: ONE global band of --bins bins (headline) split over the N ranks by cost (dist.balanced_shards), the
+per-rank solve / reduce times in the line, so that imbalance is visible; default "weak": --bins bins per rank.
 --dry-run: CPU rehearsal of the multi-rank path (gloo, fabricated partials, no solver) used by tests/test_dist_cpu.py.
 """
 import argparse
@@ -88,6 +93,65 @@ def cpu_baseline(wl, nsample):
     return dict(value=done / dt, unit="bins/s", cores=1, kind=kind,
                 sample="first %d bins of the bench batch, serial SOS_OS calls (%s), %.1f s" % (
                     done, "amdflang -O2 build of the reference Fortran" if kind == "reference" else "C restatement -O2", dt))
+
+
+def cpu_worker(args):
+    """One process of the all-cores CPU baseline: the same serial SOS_OS calls as cpu_baseline on a slice of the bench batch,
+    for about `--cpu-seconds` seconds; prints `done elapsed kind`."""
+    pkg = importlib.import_module("radiativetransfer-sos_amd")
+    from oracle import oracle_ctypes, ref_ctypes
+    kind, mod = "port", oracle_ctypes
+    if ref_ctypes.available():
+        try:
+            ref_ctypes.lib()
+            kind, mod = "reference", ref_ctypes
+        except OSError:
+            pass
+    nb = 96
+    wl = build_workload(pkg.synth, args.bins, args.nt, 1234, args.g, part=(args.cpu_worker * nb, (args.cpu_worker + 1) * nb))
+    al, be, ga, ze = wl["coefs"]
+    kw = dict(n0=wl["n0"], ro=0.1, iborm=wl["iborm"])
+    if kind == "reference":
+        kw["want_log"] = False
+    mod.sos_os(wl["mu"], wl["w"], wl["os_nb"], wl["h"][0], wl["xdel"][0], wl["ydel"][0], al, be, ga, ze, zprof=wl["zprof"][0], **kw)
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        b = done % nb
+        mod.sos_os(wl["mu"], wl["w"], wl["os_nb"], wl["h"][b], wl["xdel"][b], wl["ydel"][b], al, be, ga, ze, zprof=wl["zprof"][b], **kw)
+        done += 1
+    print("CPUWORKER %d %.3f %s" % (done, time.perf_counter() - t0, kind))
+
+
+def cpu_baseline_all_cores(seconds):
+    """The reference on ALL host cores of the box: one PROCESS per core, each with its own temporary directory (the Fortran is
+    not re-entrant: fixed unit numbers and temporary file names, SOS_PROC.F:1460-1466 -- so processes, not threads), the
+    serial SOS_OS calls of cpu_baseline on different slices of the bench batch, all running for the same wall time.
+    Started before this process touches the GPU; collected by finish_cpu_all_cores()."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-seconds", str(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(cores)]
+    return procs
+
+
+def finish_cpu_all_cores(procs):
+    done, tmax, kind = 0, 0.0, "port"
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        for ln in out.splitlines():
+            if ln.startswith("CPUWORKER"):
+                _, d, t, kind = ln.split()
+                done += int(d)
+                tmax = max(tmax, float(t))
+    if not tmax:
+        return None
+    return dict(value=done / tmax, unit="bins/s", cores=len(procs), kind=kind,
+                sample="%d processes (one per host core), each serial SOS_OS calls on its own 96-bin slice of the bench batch for "
+                       "%.1f s: %d bins in all" % (len(procs), tmax, done))
 
 
 def _free_port():
@@ -178,7 +242,7 @@ def pmc_traffic(tag, **match):
     return None
 
 
-def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g):
+def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g, strong=False):
     """The level grids real CKD bins get (NT >= CTE_OS_NT_MIN = 100, SOS.h:229): profiles made on the device by
     sosgpu_profile from seeded gas columns, solved by the streamed-field variant.  Returns the result dict."""
     S = pkg.synth
@@ -186,14 +250,18 @@ def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g):
     os_nb = 80
     al, be, ga, ze = S.hg_phase(os_nb, g)
     cx = pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=os_nb, ro=0.1)
-    nb_tot = nbins * world
-    lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
+    strong = strong and world > 1
+    nb_tot = nbins if strong else nbins * world
     alt, tabs = realistic_columns(nb_tot)
     aik_all = np.random.default_rng(1234).dirichlet(np.ones(nb_tot))
-    order = np.argsort(-tabs[lo:hi, -1], kind="stable")           # cost-sorted (thickest gas column first)
-    bins = cx.make_profiles(hi - lo, 0.0948, 8.0, 0.3, 2.0, alt, tabs[lo:hi][order], piz=0.95, piztr=0.95)
-    aik = torch.from_numpy(aik_all[lo:hi][order]).to(cx.device)
-    out = cx.alloc_outputs(hi - lo)
+    if strong:          # one band dealt to the ranks by cost (levels x scattering steps, dist.bin_cost)
+        sel = pkg.dist.balanced_shards(pkg.dist.bin_cost(0.0948 + 0.3, tabs[:, -1]), world)[rank]
+    else:
+        sel = np.arange(*pkg.dist.shard_range(nb_tot, rank, world))
+    order = np.argsort(-tabs[sel, -1], kind="stable")             # cost-sorted (thickest gas column first)
+    bins = cx.make_profiles(len(sel), 0.0948, 8.0, 0.3, 2.0, alt, tabs[sel][order], piz=0.95, piztr=0.95)
+    aik = torch.from_numpy(aik_all[sel][order]).to(cx.device)
+    out = cx.alloc_outputs(len(sel))
     torch.cuda.synchronize()
 
     def step():
@@ -224,7 +292,7 @@ def run_realistic(pkg, torch, dist, world, rank, nbins, steps, warmup, g):
                config=dict(workload="same wavelength as the headline, level grids of SOS_PROFILE for seeded gas columns "
                                     "(k log-uniform 1e-3..30): NT %d...%d, mean %.0f; %d bins/GPU/step" % (
                                         nt.min(), nt.max(), nt.mean(), nbins),
-                           bins_per_gpu=nbins, nt_min=int(nt.min()), nt_mean=float(nt.mean()), nt_max=int(nt.max()),
+                           bins_per_gpu=len(sel), nt_min=int(nt.min()), nt_mean=float(nt.mean()), nt_max=int(nt.max()),
                            mean_fourier_orders=float(nord.mean()), mean_scattering_steps=float(nsteps.mean())),
                roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                              traffic=pmc_traffic("_realistic", bins_per_gpu=nbins),
@@ -263,12 +331,24 @@ def small_band_latency(pkg, torch, g, nbins=25):
 
 
 def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup, args, base):
-    """One measurement of the headline workload with `nbins` CKD bins per GPU and step: returns (result dict, workload, per-bin
-    Fourier-order counts)."""
-    # every rank owns `nbins` bins of one global band of world*nbins bins (weights normalised globally)
-    nb_tot = nbins * world
-    lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
-    wl = build_workload(S, nb_tot, args.nt, 1234, args.g, part=(lo, hi))
+    """One measurement of the headline workload: returns (result dict, workload, per-bin Fourier-order counts).
+    weak scaling: every rank owns `nbins` bins of one global band of world * nbins bins (weights normalised globally);
+    strong scaling (args.scaling): ONE band of `nbins` bins, dealt to the ranks by cost (dist.balanced_shards)."""
+    strong = getattr(args, "scaling", "weak") == "strong" and world > 1
+    if strong:
+        nb_tot = nbins
+        full = S.ckd_bins(nb_tot, args.nt, seed=1234)
+        costs = pkg.dist.bin_cost(0.3948, np.maximum(full["h"][:, -1] - 0.3948, 0.0), fixed_levels=True)
+        mine = pkg.dist.balanced_shards(costs, world)[rank]
+        wl = build_workload(S, nb_tot, args.nt, 1234, args.g)
+        for k in ("h", "xdel", "ydel", "zprof", "aik"):
+            wl[k] = wl[k][mine]
+        nloc = len(mine)
+    else:
+        nb_tot = nbins * world
+        lo, hi = pkg.dist.shard_range(nb_tot, rank, world)
+        wl = build_workload(S, nb_tot, args.nt, 1234, args.g, part=(lo, hi))
+        nloc = hi - lo
     al, be, ga, ze = wl["coefs"]
     cx = pkg.SosContext(wl["mu"], wl["w"], wl["n0"], al, be, ga, ze, iborm_max=wl["iborm"], ro=0.1, device=dev)
     bins = cx.upload_bins(wl["h"], wl["xdel"], wl["ydel"], order=None if args.no_sort else "cost")
@@ -276,7 +356,7 @@ def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup
     if bins["perm"] is not None:
         aik_h = aik_h[bins["perm"]]
     aik = torch.from_numpy(aik_h).to(cx.device)
-    out = cx.alloc_outputs(hi - lo)
+    out = cx.alloc_outputs(nloc)
     torch.cuda.synchronize()
 
     def step():
@@ -302,7 +382,7 @@ def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup
     res = dict(base, value=nb_tot * steps / dt, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
                config=dict(workload="single-wavelength aerosol+Rayleigh, 40 Gauss angles (N=41), NT=%d layers, OS_NB=80, "
                                     "Lambertian rho=0.1, HG g=%.2f, %d CKD bins/GPU/step" % (args.nt, args.g, nbins),
-                           bins_per_gpu=nbins, nt=args.nt, n_dirs=41, os_nb=80, parallelism="bins sharded x%d" % world,
+                           bins_per_gpu=nloc if strong else nbins, nt=args.nt, n_dirs=41, os_nb=80, parallelism="bins sharded x%d" % world,
                            bin_order="generation" if args.no_sort else "cost-sorted"),
                roofline=dict(bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
@@ -310,9 +390,102 @@ def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup
                              flops_counted="parity form (two 3N x 3Nw half systems, Nw = weighted directions) + rank-4 molecular form + formal solution, unpadded",
                              reference_algorithm_flops_per_launch=flops_ref,
                              reference_algorithm_tflops=flops_ref / (kern_ms * 1e-3) / 1e12))
+    if world > 1:
+        # per-rank solve and reduce times (imbalance shows here): kernel time of the rank's own solve from its HIP events, the
+        # band all-reduce timed on its own after a barrier
+        rec, scal = cx.aggregate(out, aik)
+        buf = pkg.dist.pack_partial(rec, scal)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            pkg.dist.all_reduce_partial(buf, scal.shape[1])
+        e1.record()
+        torch.cuda.synchronize()
+        mine_t = torch.tensor([kern_ms, e0.elapsed_time(e1) / 5.0, float(nloc)], dtype=torch.float64, device=cx.device)
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        res["per_rank"] = dict(solve_ms=[float(t[0]) for t in allt], reduce_ms=[float(t[1]) for t in allt],
+                               bins=[int(t[2]) for t in allt])
+    res["scaling"] = "strong" if strong else "weak"
+    if strong:
+        res["config"]["parallelism"] = "one band of %d bins dealt to %d ranks by cost" % (nb_tot, world)
     nord = out["norders"].cpu().numpy()
     cx.close()
     return res, wl, nord
+
+
+def measure_variant(pkg, S, torch, name, nbins, kw, nt=30, g=0.75):
+    """The headline workload with another surface (BASELINE configs 3 and 4: the SURF / Fresnel variants of k_sos_os), kernel
+    time from HIP events, executed-flops roofline fraction."""
+    mu, w, n0 = S.gauss_angles(40, 35.0)
+    os_nb = 80
+    al, be, ga, ze = S.hg_phase(os_nb, g)
+    b = S.ckd_bins(nbins, nt, seed=1234)
+    h, x, y, iborm = S.rescale_profile(b["h"], b["xdel"], b["ydel"], 0.0, 0.95, 0.95, os_nb)
+    if kw.get("imat_surf"):
+        kw = dict(kw, rsurf=pkg.surface.glitter_matrices(mu, w, 7.0, 1.34, iborm, os_nb, 2 * os_nb)["rsurf"][:iborm + 1])
+    cx = pkg.SosContext(mu, w, n0, al, be, ga, ze, iborm_max=iborm, **kw)
+    bins = cx.upload_bins(h, x, y, order="cost")
+    out = cx.alloc_outputs(nbins)
+    cx.solve(bins, out)
+    torch.cuda.synchronize()
+    kms = kernel_ms(cx, bins, out)
+    _, flops_exe = cx.solve_flops(bins, out)
+    tf = flops_exe / (kms * 1e-3) / 1e12
+    res = dict(workload=name, value=nbins / (kms * 1e-3), unit="bins/s", bins=nbins, kernel_ms=kms, mfma_tflops=tf,
+               roofline_frac=tf / FP64_PEAK_TFLOPS, mean_fourier_orders=float(out["norders"].float().mean()))
+    cx.close()
+    return res
+
+
+def hyperspectral_kwargs(rs, every=1):
+    """sos_proc keyword sets of BASELINE config 5: one call per 10 cm-1 interval of 2500-27500 cm-1 (the wavelengths SOS_PROC
+    accepts, 0.364-4 um), all gases, mid-latitude summer + user CO2 / CH4, log-normal aerosol, Roujean + Maignan surface."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import hyperspectral_bench
+    return hyperspectral_bench.spectrum_kwargs(rs, every)
+
+
+def run_hyperspectral(pkg, torch, dist, world, rank, every=1):
+    """BASELINE config 5 through run_sos.sos_spectrum; with N ranks the wavelengths are dealt to the ranks by cost and the
+    results gathered (no all-reduce).  Synthetic CKD tables are written once per rank (scripts/synth_ckd.py)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import synth_ckd
+    rs = pkg.run_sos
+    root = tempfile.mkdtemp(prefix="synth_fic_")
+    synth_ckd.write_tables(root)
+    os.environ["SOS_ABS_ROOT"] = root
+    kws = hyperspectral_kwargs(rs, every)
+    nb = sum(pkg.absorption.band_bin_count(kw["wa_simu"], 10.0) for kw in kws)
+    rs.sos_spectrum(kws[:16], gather=False)                  # warm-up: library, surface matrices, Mie records, table parsing
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tm = {}
+    t0 = time.perf_counter()
+    rs.sos_spectrum(kws, timings=tm, gather=world > 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    nmine = max(1, len(kws) // world)
+    host = (tm["prepare"] + tm["solve_launch"] + tm["finish"]) / nmine
+    wait = (tm["wait"] + tm["trphi"]) / nmine
+    return dict(value=nb / dt, unit="bins/s", wavelengths_per_s=len(kws) / dt, wavelengths=len(kws), bins=nb, seconds=dt,
+                host_ms_per_wavelength=1e3 * host, gpu_wait_ms_per_wavelength=1e3 * wait,
+                host_phases_ms_per_wavelength={k: 1e3 * v / nmine for k, v in tm.items()},
+                config=dict(workload="hyperspectral 2500-27500 cm-1 in 10 cm-1 intervals through run_sos.sos_spectrum: %d "
+                                     "wavelengths, %d CKD bins (1...125 per wavelength; synthetic tables with the reference's "
+                                     "exponential-term counts), all gases, LND aerosol by Mie theory per wavelength, Roujean + "
+                                     "Maignan surface, 16 Gauss angles, polar view" % (len(kws), nb),
+                            parallelism="wavelengths dealt to %d rank(s) by cost, results gathered" % world))
 
 
 def main():
@@ -323,7 +496,13 @@ def main():
     ap.add_argument("--bins", type=int, default=32768, help="CKD bins per GPU per step (records: 161 KB of HBM per bin)")
     ap.add_argument("--nt", type=int, default=30)
     ap.add_argument("--g", type=float, default=0.75)
-    ap.add_argument("--workload", choices=["headline", "realistic"], default="headline")
+    ap.add_argument("--workload", choices=["headline", "realistic", "hyperspectral"], default="headline")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --bins bins per GPU; strong: one band of --bins bins split over the GPUs by cost")
+    ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time of the all-cores CPU baseline")
+    ap.add_argument("--no-hyper", action="store_true", help="skip the appended hyperspectral measurement (N = 1 default run)")
+    ap.add_argument("--spectrum-every", type=int, default=1, help="hyperspectral: take every k-th spectral interval")
     ap.add_argument("--cpu-sample", type=int, default=224, help="bins timed on the CPU baseline (about 15 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mix", action="store_true", help="skip the appended realistic_mix measurement (N = 1 default run)")
@@ -331,6 +510,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank path (gloo, no solver)")
     args = ap.parse_args()
 
+    if args.cpu_worker >= 0:
+        cpu_worker(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,6 +524,11 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29511")
     if args.dry_run:
         sys.exit(dry_run(args, world, rank))
+    # the all-cores CPU baseline runs in child processes started BEFORE this process initialises the GPU, while the main
+    # process imports torch and builds its workload (its ~12 s overlap the GPU warm-up, not the timed steps: collected first)
+    cpu_procs = None
+    if world == 1 and rank == 0 and not args.no_cpu and args.workload == "headline":
+        cpu_procs = cpu_baseline_all_cores(args.cpu_seconds)
 
     import torch
     import torch.distributed as dist
@@ -357,13 +544,23 @@ def main():
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic")
 
     if args.workload == "realistic":
-        r = run_realistic(pkg, torch, dist, world, rank, args.bins, args.steps, args.warmup, args.g)
+        r = run_realistic(pkg, torch, dist, world, rank, args.bins, args.steps, args.warmup, args.g, strong=args.scaling == "strong")
         r["config"]["parallelism"] = "bins sharded x%d" % world
+        if args.scaling == "strong" and world > 1:
+            r["scaling"] = "strong"
         if rank == 0:
             print(json.dumps(dict(base, **r)))
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.workload == "hyperspectral":
+        r = run_hyperspectral(pkg, torch, dist, world, rank, args.spectrum_every)
+        if rank == 0:
+            print(json.dumps(dict(base, scaling="strong", steps=1, warmup=1, ms_per_step=1e3 * r["seconds"], **r)))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    cpu_all = finish_cpu_all_cores(cpu_procs) if cpu_procs else None      # (before the timed steps: the host is quiet again)
 
     res, wl, nord = measure_headline(pkg, S, torch, dist, world, rank, dev, args.bins, args.steps, args.warmup, args, base)
     if world == 1 and not args.no_mix:
@@ -376,10 +573,19 @@ def main():
                                      kernel_ms=sm["roofline"]["kernel_ms"])
         res["realistic_mix"] = run_realistic(pkg, torch, dist, world, rank, SMALL_BATCH, max(3, args.steps // 3), 2, args.g)
         res["small_band"] = small_band_latency(pkg, torch, args.g)
+        # BASELINE configs 3 and 4 on the same synthetic band: the Fresnel and the surface-matrix (SURF) variants of k_sos_os
+        res["variants"] = [measure_variant(pkg, S, torch, "cfg3 flat sea (Fresnel interface, n = 1.34)", SMALL_BATCH,
+                                           dict(ro=0.02, ifresnel=1, ind_surf=1.34)),
+                           measure_variant(pkg, S, torch, "cfg4 Cox-Munk glitter 7 m/s (surface matrices, ground_mfma)", SMALL_BATCH,
+                                           dict(ro=0.0, imat_surf=1))]
+        if not args.no_hyper:
+            res["hyperspectral"] = run_hyperspectral(pkg, torch, dist, world, rank, args.spectrum_every)
     if rank == 0:
         res["config"]["mean_fourier_orders"] = float(nord.mean())
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample)
+            if cpu_all:
+                res["cpu_baseline"]["all_cores"] = cpu_all
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

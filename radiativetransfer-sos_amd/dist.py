@@ -21,7 +21,7 @@ def shard_range(nb, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def bin_cost(tau_scat, tau_abs):
+def bin_cost(tau_scat, tau_abs, fixed_levels=False):
     """Relative cost of one CKD bin on the solver, from what the host knows before any profile exists: the scattering optical
     depth of the wavelength (Rayleigh + aerosol) and the bin's total gas absorption optical depth.  Cost = levels x scattering
     steps: SOS_PROFILE lays a level every CTE_TCOUCHE = 0.005 of total optical depth between CTE_OS_NT_MIN = 100 and CTE_OS_NT
@@ -34,6 +34,8 @@ def bin_cost(tau_scat, tau_abs):
     # in a weak bin; a strong bin (tau_gas > 1.5) gets the levels of about one unit of gas; never below ~117
     nt = np.clip(1.12 * (ts + np.where(tg > 1.5, 1.0, tg)) / 0.005, 117.0, 600.0)
     steps = 1.0 / (1.0 + 0.12 * np.power(np.minimum(tg, 50.0), 0.7))
+    if fixed_levels:                               # synthetic bands on one fixed level grid: only the scattering steps vary
+        return steps + 0. * ts
     return nt * steps
 
 
