@@ -132,6 +132,8 @@ def cpu_baseline_all_cores(seconds):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a share of 16 host cores (its affinity mask shows the whole machine): stay inside it
+    cores = max(1, min(cores, int(os.environ.get("SOS_BENCH_CPU_CORES", "16"))))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-seconds", str(seconds)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(cores)]

@@ -310,6 +310,9 @@ int  sosgpu_granu(int device, int nbmu, int nalpha, const float *d_rec, int igra
  * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.
  * The shipped build never writes it. */
 int  sosgpu_debug_phase_buffer(sosgpu_ctx *cx, unsigned long long *d_phase);
+/* Diagnostic accessor: device pointer and size (doubles) of the streamed solver's scratch of this context, and the offset of the
+ * order-parallel form's I3 hand-over block [nb][iborm_max+1][threads] inside it after such a solve (0 otherwise). */
+int  sosgpu_debug_scratch(sosgpu_ctx *cx, double **d_scratch, size_t *doubles, size_t *spec_i3_offset);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ EXPORTS = [
     "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_set_surface_matrices_async", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
-    "sosgpu_debug_phase_buffer", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
+    "sosgpu_debug_phase_buffer", "sosgpu_debug_scratch", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
     "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce", "sosgpu_absprofile", "sosgpu_land_surface", "sosgpu_mie", "sosgpu_granu",
     "sosgpu_ctx_table_entry_bytes", "sosgpu_ctx_table", "sosgpu_os_solve_multi", "sosgpu_trim",
 ]
@@ -129,6 +129,8 @@ def lib():
         L.sosgpu_land_surface.argtypes = [i32, C.POINTER(Land), i32, vp, vp, dbl, i32, i32, i32, vp, C.POINTER(C.c_int32), vp]
         L.sosgpu_debug_phase_buffer.restype = i32
         L.sosgpu_debug_phase_buffer.argtypes = [vp, vp]
+        L.sosgpu_debug_scratch.restype = i32
+        L.sosgpu_debug_scratch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 

@@ -41,6 +41,7 @@ struct sosgpu_ctx {
     double *prof_ng;        // [4][608] no-gas profile of the wavelength (sosgpu_profile)
     double *gnd_op, *gnd_dir;   // packed ground-reflection operators / solar-beam columns of the surface matrices (context-owned)
     size_t scratch_doubles;
+    size_t dbg_spec_i3;     // offset of the order-parallel form's I3 block in the scratch of the last solve (diagnostic)
 };
 
 extern "C" const char *sosgpu_version(void) { return "sosgpu 0.1 (gfx950)"; }
@@ -211,6 +212,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->ind_surf = wv->ind_surf;
     cx->scratch = nullptr;
     cx->scratch_doubles = 0;
+    cx->dbg_spec_i3 = 0;
     cx->phase = nullptr;
     cx->agg_partial = nullptr;
     cx->prof_ng = nullptr;
@@ -614,6 +616,7 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
         if (big && spec_k) {
             // order-parallel form: set-up launch, then rounds of (K order tasks per bin, replay of their stop tests)
             bn.spec_i3 = cx->scratch + per_bin * (size_t)nb * spec_k;
+            cx->dbg_spec_i3 = per_bin * (size_t)nb * spec_k;
             const int nt_max_r = lpb - 1;              // level capacity of the regions (>= every valid NT of the batch)
             bn.spec_k = -spec_k; bn.s_begin = 0; bn.s_end = 0;
             rc = launch_sos_stream(cx->d, bn, nt_max_r, st, &g_last_hip);
@@ -1274,6 +1277,17 @@ extern "C" int sosgpu_granu(int device, int nbmu, int nalpha, const float *d_rec
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     else (void)hipStreamSynchronize(st);
     HIPCHK(e);
+    return SOSGPU_OK;
+}
+
+// Diagnostic: the streamed solver's scratch of this context (device pointer, size in doubles) and, after an order-parallel
+// solve, where its I3 hand-over block starts (doubles from the start; 0 when the last solve did not use that form).
+extern "C" int sosgpu_debug_scratch(sosgpu_ctx *cx, double **d_scratch, size_t *doubles, size_t *spec_i3_offset)
+{
+    if (!cx || !d_scratch || !doubles || !spec_i3_offset) return SOSGPU_E_ARG;
+    *d_scratch = cx->scratch;
+    *doubles = cx->scratch_doubles;
+    *spec_i3_offset = cx->dbg_spec_i3;
     return SOSGPU_OK;
 }
 

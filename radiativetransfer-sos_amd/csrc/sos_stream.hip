@@ -686,10 +686,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         if (t == 0) bn.iglast[(size_t)b * S1 + s] = iglast;
         nord = s + 1;
         // (The order loop is left by its regular exits also in this form: the test below then runs on partial sums and its
-        //  result is not used.  A `break` right here made the <4,2,ZO,SURF> variant -- 63 spilled VGPRs -- hand the replay
-        //  I3 terms that stopped the series early although its records were right; not understood, test
-        //  test_streamed_order_parallel_form_equals_per_bin_launch[1-25-80-True-True-0] is the witness.)
+        //  result is not used.  A `break` right here (-DSOS_EXP_SPEC_BREAK) makes the <4,2,ZO,SURF> instantiation -- 365 spilled
+        //  SGPRs, 86 spilled VGPRs in that build -- store I3 = 0 for every DOWN-going row (waves 2, 3) and a wrong value for
+        //  thread 0, so that the replay stops the series after 9 orders instead of 31: reproduced and dumped with
+        //  scripts/spec_break_probe.py (round 3).  The source has no path on which a down-going row's I3 is zero there: the
+        //  value is lost between the scattering-order loop and the store by the compiler's register allocation of that
+        //  build (the store itself, its address and its exec mask are right in the ISA), not by a race -- the dump is
+        //  deterministic and wave-uniform.  The shipped exit keeps I3 live into the stop test, which every instantiation
+        //  needs anyway; the hand-over is checked against the per-bin launch for ALL twelve (NW, RTWH, ZO, SURF)
+        //  instantiations with several rounds: tests/test_gpu_parity.py, _ALL_VARIANTS.)
         if (spec) bn.spec_i3[((size_t)b * S1 + s) * NTH + t] = i3;
+#ifdef SOS_EXP_SPEC_BREAK
+        if (spec) break;          // diagnostic build: the exit that made <4,2,ZO,SURF> hand over wrong I3 terms
+#endif
         PH(6);
         const double a3 = fabs(i3);                                                                 // SOS_ARRET_FOURIER
         const bool pf = active && ((i4 != 0.0 && a3 > cx.thr_sf * fabs(i4)) || (i5 != 0.0 && a3 > cx.thr_sf * fabs(i5)));

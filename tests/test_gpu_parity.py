@@ -382,9 +382,14 @@ def test_streamed_persistent_many_bins_bitwise_equal_to_per_bin_launch(gpu_pkg, 
     cx.close()
 
 
+# every (NW, RTWH, ZO, SURF) instantiation of k_sos_stream -- N = 13: <4,1>, N = 25: <4,2>, N = 49: <8,2> -- with K forced so that
+# a bin needs several rounds of order tasks + replay (the hand-over of the I3 terms must be checked in every variant)
+_ALL_VARIANTS = [(3, n, 24, surf, zout, 4) for n in (13, 25, 49) for surf in (False, True) for zout in (False, True)]
+
+
 @pytest.mark.parametrize("nb,n,os_nb,surf,zout,k", [(1, 13, 24, False, False, 0), (37, 13, 24, False, False, 0),
                                                     (100, 13, 24, True, False, 0), (1, 25, 80, True, True, 0),
-                                                    (3, 25, 80, True, True, 5), (2, 41, 48, False, True, 7)])
+                                                    (3, 25, 80, True, True, 5), (2, 41, 48, False, True, 7)] + _ALL_VARIANTS)
 def test_streamed_order_parallel_form_equals_per_bin_launch(gpu_pkg, monkeypatch, nb, n, os_nb, surf, zout, k):
     """Few bins: the Fourier orders of a bin run as independent workgroups and the stop tests are replayed afterwards (one
     round of all orders for 1 bin, several rounds of K orders for 100 bins or with K forced).  Records of the orders a bin ran,
