@@ -689,12 +689,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         //  result is not used.  A `break` right here (-DSOS_EXP_SPEC_BREAK) makes the <4,2,ZO,SURF> instantiation -- 365 spilled
         //  SGPRs, 86 spilled VGPRs in that build -- store I3 = 0 for every DOWN-going row (waves 2, 3) and a wrong value for
         //  thread 0, so that the replay stops the series after 9 orders instead of 31: reproduced and dumped with
-        //  scripts/spec_break_probe.py (round 3).  The source has no path on which a down-going row's I3 is zero there: the
-        //  value is lost between the scattering-order loop and the store by the compiler's register allocation of that
-        //  build (the store itself, its address and its exec mask are right in the ISA), not by a race -- the dump is
-        //  deterministic and wave-uniform.  The shipped exit keeps I3 live into the stop test, which every instantiation
-        //  needs anyway; the hand-over is checked against the per-bin launch for ALL twelve (NW, RTWH, ZO, SURF)
-        //  instantiations with several rounds: tests/test_gpu_parity.py, _ALL_VARIANTS.)
+        //  scripts/spec_break_probe.py (round 3).  The dump is deterministic and wave-uniform (all of waves 2 and 3, nothing of
+        //  waves 0 and 1 but thread 0), so it is not a race; the source has no path on which a down-going row's I3 is zero
+        //  there; in that build's ISA the store, its address (SGPR pair restored from VGPR lanes) and its exec mask are right
+        //  and the stored register pair is one the allocator shares between xb and i3 -- where its last definition for the
+        //  down-going waves is lost was not traced through the 24 000 lines.  The shipped exit keeps I3 live into the stop
+        //  test, which every instantiation needs anyway, and the hand-over is checked against the per-bin launch for ALL
+        //  twelve (NW, RTWH, ZO, SURF) instantiations with several rounds: tests/test_gpu_parity.py, _ALL_VARIANTS.)
         if (spec) bn.spec_i3[((size_t)b * S1 + s) * NTH + t] = i3;
 #ifdef SOS_EXP_SPEC_BREAK
         if (spec) break;          // diagnostic build: the exit that made <4,2,ZO,SURF> hand over wrong I3 terms
