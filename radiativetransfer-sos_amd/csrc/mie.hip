@@ -242,44 +242,39 @@ __global__ void k_granu(int na, int nbmu, const float *__restrict__ rec, int igr
     __syncthreads();
     const int nuse = s_nuse;
     __shared__ double s_k[3];
-    // pass 2: tiles of GT records go through LDS (coalesced loads); thread o then adds its column of the tile in record order.
-    // One thread per output: 3 W phase-function sums + the three scalar sums (o = 0..2 read the work arrays).
-    constexpr int GT = 32;
-    extern __shared__ double lds[];
-    double *t_ws = lds;                                     // [GT] qsca x1 of the tile
-    double *t_sc = t_ws + GT;                               // [GT][2] x1 qext | nr pr
-    float *t_rec = reinterpret_cast<float *>(t_sc + 2 * GT);   // [GT][3 W] phase-function entries
+    // pass 2: one thread per output (3 W phase-function sums + the three scalar sums) adds its column in record order.  The
+    // loads do not depend on the running sum: UB records are requested together (coalesced over the threads: the 3 W entries
+    // of a record are contiguous), then added one after the other -- the serial chain is the additions only.
+    constexpr int UB = 24;
     const int NO = 3 * W + 3;
-    double acc[2] = {0., 0.};                               // outputs t and t + blockDim.x (3 W + 3 <= 2 blockDim.x)
-    for (int i0 = 0; i0 < nuse; i0 += GT) {
-        const int cnt = min(GT, nuse - i0);
-        __syncthreads();
-        for (int e = t; e < cnt * 3 * W; e += blockDim.x) {
-            const int i = e / (3 * W), c = e - i * 3 * W;
-            t_rec[i * 3 * W + c] = rec[(size_t)(i0 + i) * RS + 4 + c];
-        }
-        for (int e = t; e < cnt; e += blockDim.x) { t_ws[e] = ws[i0 + e]; t_sc[2 * e] = wq[i0 + e]; t_sc[2 * e + 1] = wn[i0 + e]; }
-        __syncthreads();
+    for (int o = t; o < NO; o += blockDim.x) {
+        double acc = 0.;
+        if (o < 3) {
+            const double *src = work + (size_t)o * na;
+            int i = 0;
+            for (; i + UB <= nuse; i += UB) {
+                double v[UB];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int o = t + u * blockDim.x;
-            if (o >= NO) continue;
-            double a = acc[u];
-            if (o == 0) for (int i = 0; i < cnt; i++) a = a + t_sc[2 * i];
-            else if (o == 1) for (int i = 0; i < cnt; i++) a = a + t_ws[i];
-            else if (o == 2) for (int i = 0; i < cnt; i++) a = a + t_sc[2 * i + 1];
-            else {
-                const float *col = t_rec + (o - 3);
-                for (int i = 0; i < cnt; i++) a = a + (double)col[i * 3 * W] * t_ws[i];
+                for (int k = 0; k < UB; k++) v[k] = src[i + k];
+#pragma unroll
+                for (int k = 0; k < UB; k++) acc = acc + v[k];
             }
-            acc[u] = a;
-        }
-    }
+            for (; i < nuse; i++) acc = acc + src[i];
+            s_k[o] = acc;
+        } else {
+            const float *col = rec + 4 + (o - 3);
+            int i = 0;
+            for (; i + UB <= nuse; i += UB) {
+                float v[UB];
+                double wv[UB];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int o = t + u * blockDim.x;
-        if (o < 3) s_k[o] = acc[u];
-        else if (o < NO) out[o] = acc[u];                   // normalised below
+                for (int k = 0; k < UB; k++) { v[k] = col[(size_t)(i + k) * RS]; wv[k] = ws[i + k]; }
+#pragma unroll
+                for (int k = 0; k < UB; k++) acc = acc + (double)v[k] * wv[k];
+            }
+            for (; i < nuse; i++) acc = acc + (double)col[(size_t)i * RS] * ws[i];
+            out[o] = acc;                                                            // normalised below
+        }
     }
     __syncthreads();
     const double kmat1 = s_k[0], kmat2 = s_k[1], somme = s_k[2];
@@ -295,7 +290,5 @@ __global__ void k_granu(int na, int nbmu, const float *__restrict__ rec, int igr
 void launch_granu(int na, int nbmu, const float *d_rec, int igranu, double v1, double v2, double v3, double wa, double alphaf,
                   double *d_work, double *d_out, hipStream_t st)
 {
-    const int W = 2 * nbmu + 1;                              // nbmu <= 100: 3 W + 3 = 606 outputs, two per thread of 320
-    const size_t lds = (size_t)(32 + 64) * sizeof(double) + (size_t)32 * 3 * W * sizeof(float);
-    k_granu<<<1, 320, lds, st>>>(na, nbmu, d_rec, igranu, v1, v2, v3, wa, alphaf, d_work, d_out);
+    k_granu<<<1, 256, 0, st>>>(na, nbmu, d_rec, igranu, v1, v2, v3, wa, alphaf, d_work, d_out);
 }

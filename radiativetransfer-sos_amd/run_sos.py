@@ -784,12 +784,14 @@ def _aerosols_at_waref(p, nb_mie, os_nb, device):
     return out
 
 
-def _prepare(kw, aer_phase=None, device=0, shard_bins=True):
+def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     """Everything of one SOS_PROC call up to the CKD bin loop (SOS_PROC.F:1310-3458): parameter checks, SOS_ANGLES,
     SOS_AEROSOLS, SOS_SURFACE, SOS_PREPA_ABSPROFILE, SOS_PREPA_OS, and the profiles of every bin of the band on the device
     (SOS_ABSPROFILE + SOS_PROFILE + the rescale of SOS).  Returns a _Plan whose `ctx` the caller closes.
     shard_bins: with torch.distributed initialised, keep only this rank's slice of the band's bins (sos_proc); False: the
-    whole band stays on this rank (sos_spectrum distributes wavelengths, not bins)."""
+    whole band stays on this rank (sos_spectrum distributes wavelengths, not bins).
+    aer_stream: HIP stream (torch.cuda.Stream) for the aerosol step, whose device calls are host-synchronous -- sos_spectrum keeps
+    them off the streams its asynchronous work is queued on."""
     missing = [k for k in SOS_PROC_KWARGS if k not in kw]
     if missing:
         raise TypeError("sos_proc() missing keyword arguments: %s" % ", ".join(missing))
@@ -854,13 +856,15 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True):
         from . import aerosols as _aer
         if p["waref_aot"] == _D:
             raise SosProcError("-AER.Waref must be defined")
+        import contextlib
         try:
-            aer_phase = _aerosols_at_waref(p, nb_mie, os_nb, device)
-            ta_model = float(p["aot_ref"])
-            if p["wa_simu"] != p["waref_aot"]:
-                k_ref = aer_phase["kmat1"]
-                aer_phase = _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device)
-                ta_model = (aer_phase["kmat1"] / k_ref) * p["aot_ref"]
+            with (torch.cuda.stream(aer_stream) if aer_stream is not None else contextlib.nullcontext()):
+                aer_phase = _aerosols_at_waref(p, nb_mie, os_nb, device)
+                ta_model = float(p["aot_ref"])
+                if p["wa_simu"] != p["waref_aot"]:
+                    k_ref = aer_phase["kmat1"]
+                    aer_phase = _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device)
+                    ta_model = (aer_phase["kmat1"] / k_ref) * p["aot_ref"]
         except _aer.AerosolError as e:
             raise SosProcError(str(e), ier=-1)
         coef_tronca_out = aer_phase["coef_tronca"]
@@ -1140,43 +1144,14 @@ def _any_rank_failed(failed, device):
 
 def sos_proc_many(kwargs_list, n_workers=8, device=0):
     """A spectrum of independent sos_proc calls (one per wavelength: the reference runs them one after the other,
-    binding/run_sos.py:640) issued from `n_workers` host threads, each on its own HIP stream.  One call spends most of its
-    wall clock waiting for the few bins of its band (a bin is a serial chain of scattering orders: milliseconds on a small
-    fraction of the chip); here the waits of one wavelength overlap the host work and the kernels of the others.  Every call
-    is the unchanged sos_proc -- results are identical to the sequential loop.  Give each call its own `-SOS_Main.ResRoot`
-    when result files are wanted (the file names inside are fixed, as in the reference).  Export GPU_MAX_HW_QUEUES=16 before
-    the first GPU call (solver.solve_many).  Returns the list of 23-tuples in order; the first failing call's exception is
-    raised after all calls have ended."""
-    import concurrent.futures
-    import torch
-    from . import capi
-    capi.lib()                                             # loaded once, before the threads
-    if not kwargs_list:
-        return []
-    if _dist_rank_world()[1] > 1:
-        raise SosProcError("sos_proc_many: with torch.distributed initialised every sos_proc call is a collective over the "
-                           "ranks (the band's bins are sharded) -- issue the calls one after the other")
-    dev = torch.device("cuda", device)
-    nw = max(1, min(int(n_workers), len(kwargs_list)))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]
-    import threading
-    slot = threading.local()
-    free = list(range(nw))
-    lock = threading.Lock()
-
-    def one(kw):
-        if not hasattr(slot, "i"):
-            with lock:
-                slot.i = free.pop()
-        with torch.cuda.device(dev), torch.cuda.stream(streams[slot.i]):
-            out = sos_proc(device=device, **kw)
-            streams[slot.i].synchronize()
-        return out
-
-    with concurrent.futures.ThreadPoolExecutor(max_workers=nw) as ex:
-        futs = [ex.submit(one, kw) for kw in kwargs_list]
-        concurrent.futures.wait(futs)
-    return [f.result() for f in futs]
+    binding/run_sos.py:640): the list interface of sos_spectrum -- identical outputs to the sequential loop, bit for bit.
+    Round 2 issued the calls from `n_workers` host threads with a HIP stream each; the Python host work under the interpreter
+    lock bounded that form at 1.3 x the plain loop (and below it once the calls became cheaper).  Now: one host thread, the
+    preparation kernels of the wavelengths spread over `n_workers` streams, all bins of all wavelengths in one launch per
+    kernel variant (sos_spectrum).  Give each call its own `-SOS_Main.ResRoot` when result files are wanted (the file names
+    inside are fixed, as in the reference).  Export GPU_MAX_HW_QUEUES=16 before the first GPU call.  Returns the list of
+    23-tuples in order; a failing call raises its exception."""
+    return sos_spectrum(kwargs_list, device=device, prep_streams=max(1, int(n_workers)))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -1243,7 +1218,7 @@ def spectrum_costs(kwargs_list):
     return costs
 
 
-def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None):
+def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None, prep_streams=8):
     """A spectrum of sos_proc calls -- one per wavelength, as the reference issues them one after the other
     (binding/run_sos.py:640-695; the bin loop of each is SOS_PROC.F:3459-3594) -- as ONE pass over the GPU:
 
@@ -1267,7 +1242,9 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     (all_gather_object of the compacted tuples), gather=False returns None in the slots of other ranks.  Result files of a
     call (-SOS_Main.ResRoot) are written by the rank that owns it.
     aer_phases: optional list parallel to kwargs_list of `aer_phase` dictionaries (see sos_proc) or None.
-    timings: optional dict, filled with host-side phase times in seconds (prepare, solve_launch, wait, trphi, finish)."""
+    timings: optional dict, filled with host-side phase times in seconds (prepare, solve_launch, wait, trphi, finish).
+    prep_streams: HIP streams the per-wavelength preparation kernels are spread over (export GPU_MAX_HW_QUEUES=16 to give them
+    hardware queues of their own, solver.solve_many)."""
     import time
     import torch
     from . import capi
@@ -1289,19 +1266,30 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     nrows = {}
     tm = dict(prepare=0.0, solve_launch=0.0, wait=0.0, trphi=0.0, finish=0.0)
     dev = torch.device("cuda", device)
+    main_st = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(prep_streams)))]
+    aer_st = torch.cuda.Stream(device=dev)
     for c0 in range(0, len(mine), max(1, int(chunk))):
         idx = mine[c0:c0 + max(1, int(chunk))]
         plans = []
         try:
             t0 = time.perf_counter()
-            for i in idx:
-                pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False)
+            # the preparation of wavelength k queues its device work (source operators, absorption and level profiles of its
+            # bins: latency-bound kernels of 0.1-2 ms on a few wavefronts) on side stream k mod n: the wavelengths overlap on the
+            # device, and the launches below wait for all of them
+            for st in side + [aer_st]:
+                st.wait_stream(main_st)
+            for k, i in enumerate(idx):
+                with torch.cuda.stream(side[k % len(side)]):
+                    pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
                 if debug:
                     torch.cuda.synchronize(dev)
                     print("[sos_spectrum] prepared", i, flush=True)
                 pl.writes_files = True
                 pl.index = i
                 plans.append(pl)
+            for st in side:
+                main_st.wait_stream(st)
             t1 = time.perf_counter()
             tm["prepare"] += t1 - t0
             # --- groups of wavelengths one launch can cover
@@ -1364,7 +1352,9 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                     k += 1
             tm["finish"] += time.perf_counter() - t4
         finally:
-            torch.cuda.current_stream(dev).synchronize()      # the table launches read every context's operators
+            for st in side:
+                st.synchronize()
+            main_st.synchronize()                             # the table launches read every context's operators
             for pl in plans:
                 pl.ctx.close()
     if timings is not None:

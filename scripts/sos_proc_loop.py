@@ -25,4 +25,8 @@ for name in ("sos_proc_cfg2_lnd_lambert", "sos_proc_cfg4_glitter_bilnd", "sos_pr
     for kw in k:
         t0 = time.perf_counter(); rs.sos_proc(**kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     ts = np.array(ts) * 1e3
-    print("%-36s 32 different calls in a plain loop: median %.1f ms, min %.1f, max %.1f, %.1f calls/s" % (name, np.median(ts), ts.min(), ts.max(), 1e3 / ts.mean()), flush=True)
+    seq = 1e3 / ts.mean()
+    rs.sos_proc_many(k[:4]); torch.cuda.synchronize()
+    t0 = time.perf_counter(); rs.sos_proc_many(k); torch.cuda.synchronize(); many = len(k) / (time.perf_counter() - t0)
+    print("%-36s 32 different calls in a plain loop: median %.1f ms, min %.1f, max %.1f, %.1f calls/s;  sos_proc_many / sos_spectrum: %.1f calls/s (%.2f x)"
+          % (name, np.median(ts), ts.min(), ts.max(), seq, many, many / seq), flush=True)
