@@ -15,7 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-val
 
 
 def _headers():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+    """What an object depends on besides its own source: every header AND every other source of csrc/ (sos_os_multi.hip and
+    sos_stream_multi.hip #include sos_os.hip / sos_stream.hip), plus the C ABI header."""
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + \
            [os.path.join(HERE, "..", "include", "sosgpu.h")]
 
 

@@ -328,6 +328,219 @@ __device__ __forceinline__ void gemm_source(v4d (&acc)[2][RTWH][CT], const doubl
 
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// SHARED-TILE form of the contraction for direction counts whose half system has MORE row tiles than waves but fewer than two
+// per wave (four waves: 5 or 6 row tiles, N = 22 ... 32 -- the reference's default of 24 Gauss angles gives N = 25, 5 tiles).
+// In gemm_source wave 0 (and 1) then carries a second tile alone: per k-pair it issues 16 MFMAs while the others issue 8 and
+// wait at the barrier.  Here every wave owns ONE row tile (tile0 = its index, both half systems, all column tiles) and the
+// R = rtph - NW left-over tiles are cut into (half system, column tile) units: wave w takes unit (usy, uct) = (w >> 1, w & 1)
+// of every left-over tile -- 8 + 2 R MFMAs per k-pair for every wave (10 instead of 16 on the critical wave at R = 1).
+// The unit's accumulators hold E^USY of one column tile only; S+ = E^A + E^B, S- = E^A - E^B of a left-over tile are formed
+// through the field buffer: the partials go to the pad rows [16 rtph, 16 rtph + 16 R) of the half USY (rows no operand,
+// sweep or projection slot ever touches: write_back_shared), and after a barrier combine_shared adds them up in place.
+// Everything else -- operand layout, software pipeline, the folded molecular projection, XDEL / YDEL scaling -- is gemm_source's.
+template <int RAY, bool FOLD, int CT, int NW, int FS, int KHM, bool PRE = false>
+__device__ __forceinline__ void gemm_source_split(v4d (&acc)[2][1][CT], v4d (&accs)[2], const int R, const int usy, const int uct,
+                                                  const double *__restrict__ mp, bool do_aer, const double *__restrict__ vt,
+                                                  const double *__restrict__ uf, int ks2h, int rtph, const double *bx,
+                                                  const double *xdel, const double *ydel, int lane, int tile0, int prow, double *pcb)
+{
+    // (usy, uct are wave-uniform run-time values: as template arguments they would quadruple the already large kernels.  The
+    //  unit's B operand X^usy of column tile uct is read from the field a second time instead of being selected out of the
+    //  registers of the own tile's operands: one or two more LDS reads per k-pair.)
+    static_assert(CT == 2 && NW == 4, "units are (half system, column tile) of four waves");
+    constexpr bool fold = FOLD;
+    struct BRaw { v2d xp[CT], xm[CT], up, um; };
+    const double *bxu = bx + uct * 16 * FS + (PRE && usy ? KHM : 0);
+    const double sgn = usy ? -1. : 1.;
+    auto load_b = [&](BRaw &b, int m) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            b.xp[ct] = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + 8 * m);
+            b.xm[ct] = *reinterpret_cast<const v2d *>(bx + ct * 16 * FS + KHM + 8 * m);
+        }
+        b.up = *reinterpret_cast<const v2d *>(bxu + 8 * m);
+        if (!PRE) b.um = *reinterpret_cast<const v2d *>(bxu + KHM + 8 * m);
+    };
+    const v2d *vp = reinterpret_cast<const v2d *>(vt) + lane;
+    const bool ray_unit = RAY >= 0 && usy == (RAY > 0 ? 1 : 0);      // this wave's unit lies in the half system the molecular operator acts on
+    v4d pr[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) pr[ct] = (v4d){0., 0., 0., 0.};
+    if (do_aer) {
+        const size_t rts = (size_t)ks2h * 64;               // v2d stride between row tiles
+        const size_t sys_stride = (size_t)rtph * rts;       // v2d stride between the two systems
+        const char *ab = reinterpret_cast<const char *>(mp) + (size_t)tile0 * rts * 16;
+        const char *sb = reinterpret_cast<const char *>(mp) + ((size_t)usy * sys_stride + (size_t)NW * rts) * 16;   // left-over tiles
+        const char *vb = reinterpret_cast<const char *>(vt);
+        unsigned loff = (unsigned)lane * 16u;
+        struct AFrag { v2d a[2]; v2d as[2]; v2d v; };
+        auto load_a = [&](AFrag &f, int m) {
+            size_t mb = (size_t)m * 1024;
+            asm volatile("" : "+v"(loff), "+s"(mb));
+#pragma unroll
+            for (int sy = 0; sy < 2; sy++) f.a[sy] = *reinterpret_cast<const v2d *>(ab + (sy * sys_stride) * 16 + mb + loff);
+            f.as[0] = *reinterpret_cast<const v2d *>(sb + mb + loff);
+            if (R > 1) f.as[1] = *reinterpret_cast<const v2d *>(sb + rts * 16 + mb + loff);
+            if (RAY >= 0 && !fold) f.v = *reinterpret_cast<const v2d *>(vb + mb + loff);
+        };
+        auto mma = [&](const AFrag &f, const BRaw &b, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const v4d zero = {0., 0., 0., 0.};
+            v2d ba[CT], bb[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                if (PRE) { ba[ct] = b.xp[ct]; bb[ct] = b.xm[ct]; }
+                else { ba[ct] = b.xp[ct] + b.xm[ct]; bb[ct] = b.xp[ct] - b.xm[ct]; }
+            }
+            v2d bu;
+            if (PRE) bu = b.up;
+            else { bu.x = __builtin_fma(sgn, b.um.x, b.up.x); bu.y = __builtin_fma(sgn, b.um.y, b.up.y); }   // X+ +- X-, exact
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                acc[0][0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0].x, ba[ct].x, FIRST ? zero : acc[0][0][ct], 0, 0, 0);
+                acc[1][0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1].x, bb[ct].x, FIRST ? zero : acc[1][0][ct], 0, 0, 0);
+            }
+            accs[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.as[0].x, bu.x, FIRST ? zero : accs[0], 0, 0, 0);
+            if (R > 1) accs[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.as[1].x, bu.x, FIRST ? zero : accs[1], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                acc[0][0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[0].y, ba[ct].y, acc[0][0][ct], 0, 0, 0);
+                acc[1][0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[1].y, bb[ct].y, acc[1][0][ct], 0, 0, 0);
+            }
+            accs[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.as[0].y, bu.y, accs[0], 0, 0, 0);
+            if (R > 1) accs[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.as[1].y, bu.y, accs[1], 0, 0, 0);
+            if (RAY >= 0 && !fold) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    const v2d bq = RAY ? bb[ct] : ba[ct];
+                    pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v.x, bq.x, pr[ct], 0, 0, 0);
+                    pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v.y, bq.y, pr[ct], 0, 0, 0);
+                }
+            }
+        };
+        const std::true_type first;
+        const std::false_type next;
+        AFrag f0, f1;
+        BRaw b0, b1;
+        load_a(f0, 0);
+        int m = 0;
+        load_b(b0, 0);
+        if (ks2h >= 2) {                                  // peeled first pair of k-pairs (as in gemm_source, PIPE_B form)
+            load_a(f1, 1);
+            load_b(b1, 1);
+            mma(f0, b0, first);
+            if (2 < ks2h) { load_a(f0, 2); load_b(b0, 2); }
+            mma(f1, b1, next);
+            m = 2;
+#pragma unroll 1
+            for (; m + 1 < ks2h; m += 2) {
+                load_a(f1, m + 1);
+                load_b(b1, m + 1);
+                mma(f0, b0, next);
+                if (m + 2 < ks2h) { load_a(f0, m + 2); load_b(b0, m + 2); }
+                mma(f1, b1, next);
+            }
+            if (m < ks2h) mma(f0, b0, next);
+        } else mma(f0, b0, first);
+        if (fold) {
+            // the projection rows sit in register 3 of the tile holding prow: this wave's own tile (all columns), or a left-over
+            // tile -- then the two waves holding the half system the molecular operator acts on publish their column each
+            const int ptile = prow >> 4;
+            if (tile0 == ptile) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    pcb[ct * 16 * FS] = acc[RAY > 0][0][ct][3];
+                    acc[RAY > 0][0][ct][3] = 0.;
+                }
+            }
+            if (ray_unit) {
+                if (ptile == NW) { pcb[uct * 16 * FS] = accs[0][3]; accs[0][3] = 0.; }
+                if (R > 1 && ptile == NW + 1) { pcb[uct * 16 * FS] = accs[1][3]; accs[1][3] = 0.; }
+            }
+        }
+        if (RAY >= 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const double sc = xdel[ct * 16 + (lane & 15)];
+                acc[0][0][ct] *= sc; acc[1][0][ct] *= sc;
+            }
+            const double su = xdel[uct * 16 + (lane & 15)];
+            accs[0] *= su;
+            if (R > 1) accs[1] *= su;
+        }
+    } else if (RAY >= 0) {
+        // molecular atmosphere: only the projections pr = V^T X^sr
+        v2d v0 = vp[0], v1;
+        BRaw b0, b1;
+        load_b(b0, 0);
+        auto prj = [&](const v2d &v, const BRaw &b) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const v2d bq = PRE ? (RAY ? b.xm[ct] : b.xp[ct]) : (RAY ? b.xp[ct] - b.xm[ct] : b.xp[ct] + b.xm[ct]);
+                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, bq.x, pr[ct], 0, 0, 0);
+                pr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, bq.y, pr[ct], 0, 0, 0);
+            }
+        };
+        int m = 0;
+#pragma unroll 1
+        for (; m + 1 < ks2h; m += 2) {
+            v1 = vp[(size_t)(m + 1) * 64];
+            load_b(b1, m + 1);
+            prj(v0, b0);
+            if (m + 2 < ks2h) { v0 = vp[(size_t)(m + 2) * 64]; load_b(b0, m + 2); }
+            prj(v1, b1);
+        }
+        if (m < ks2h) prj(v0, b0);
+    }
+    if (RAY >= 0) {
+        if (fold) __syncthreads();             // every wave of the workgroup passes exactly one barrier here (see the call site)
+        double qu = 0.;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const double q = (fold ? pcb[ct * 16 * FS] : pr[ct][0]) * ydel[ct * 16 + (lane & 15)];
+            const double u = uf[(size_t)tile0 * 64 + lane];
+            acc[RAY > 0][0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, q, acc[RAY > 0][0][ct], 0, 0, 0);
+            if (ct == uct) qu = q;
+        }
+        if (ray_unit) {
+            accs[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[(size_t)NW * 64 + lane], qu, accs[0], 0, 0, 0);
+            if (R > 1) accs[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[(size_t)(NW + 1) * 64 + lane], qu, accs[1], 0, 0, 0);
+        }
+    }
+}
+
+// Partials of the left-over tiles -> pad rows of the field buffer: unit (USY, UCT) of left-over tile r goes to rows
+// 16 rtph + 16 r ... of the half USY, columns of column tile UCT (lane: column lane&15, rows 4e + (lane>>4)).
+// xdel != nullptr: the accumulators are still unscaled (s > 2).
+template <int FS, int KHM>
+__device__ __forceinline__ void write_back_shared(const v4d (&accs)[2], int R, int usy, int uct, double *cbuf, int lane, int rtph,
+                                                  const double *xdel)
+{
+    double *wb = cbuf + (size_t)(uct * 16 + (lane & 15)) * FS + usy * KHM + 16 * rtph + (lane >> 4);
+    const double sc = xdel ? xdel[uct * 16 + (lane & 15)] : 1.0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        wb[4 * e] = xdel ? sc * accs[0][e] : accs[0][e];
+        if (R > 1) wb[16 + 4 * e] = xdel ? sc * accs[1][e] : accs[1][e];
+    }
+}
+
+// S+ = E^A + E^B, S- = E^A - E^B of the left-over tiles (rows 16 NW ... 16 rtph of both halves) from the partials in the pad
+// rows; NTH threads, one pass, consecutive threads on consecutive rows.  A barrier before (partials written) and after.
+template <int NW, int FS, int KHM, int COLS>
+__device__ __forceinline__ void combine_shared(double *cbuf, int t, int nth, int rtph)
+{
+    const int nrow = 16 * (rtph - NW);
+    for (int i = t; i < nrow * COLS; i += nth) {
+        const int col = i / nrow, row = i - col * nrow;
+        double *c = cbuf + (size_t)col * FS;
+        const double a = c[16 * rtph + row], b = c[KHM + 16 * rtph + row];
+        c[16 * NW + row] = a + b;
+        c[KHM + 16 * NW + row] = a - b;
+    }
+}
+
 // Parity combination of the whole field buffer in place, once per step (flagship: between the stop tests and the contraction;
 // one more workgroup barrier after it): wave w takes levels w, w + NW, ..., a lane two adjacent rows of both halves.
 template <int NW, int FS, int KHM, int LEVELS>

@@ -54,7 +54,7 @@
 #else
 #define SOS_MIN_WG(NW, CT) (((NW) == 4) ? 2 : 1)
 #endif
-template <int NW, int RTWH, int CT, bool ZO, bool SURF>
+template <int NW, int RTWH, int CT, bool ZO, bool SURF, bool SPLIT>
 __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const SosDev cx_arg, const SosBins bn)
 {
     SOS_BIND_CTX(cx, cx_arg, bn);
@@ -100,6 +100,12 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
     const int recoff = c * W + N + (up ? (jj + 1) : -(jj + 1));
     const size_t mper = (size_t)2 * cx.rtph * cx.ks2h * 128;
     const int S1 = cx.smax + 1;
+    // shared-tile form of the contraction (sos_dev.h gemm_source_split): four waves, five or six row tiles (N = 22 ... 32).
+    // A template argument, chosen by the launcher from the context's tile count (sos_split_applies): an instantiation of its own,
+    // so that the kernels of the other direction counts are compiled exactly as without it.
+    constexpr bool SPLIT_OK = SPLIT;
+    static_assert(!SPLIT || (NW == 4 && RTWH == 2 && CT == 2), "shared-tile form: four waves, two column tiles");
+    constexpr bool split = SPLIT;
     // contraction tiles of this wave: tile wv, and tile wv + NW for the larger N of a variant (wave-uniform)
     const bool tile_a = wv * 16 < KH;
     const bool tile_b = RTWH > 1 && (wv + NW) * 16 < KH;
@@ -331,13 +337,44 @@ __global__ __launch_bounds__(64 * NW, SOS_MIN_WG(NW, CT)) void k_sos_os(const So
                         else { if (fold) SOS_GEMM(0, true); else SOS_GEMM(0, false); }
 #undef SOS_GEMM
                     };
-                    if (tile_b) contract(std::integral_constant<int, RTWH>());
-                    else if (tile_a) contract(std::integral_constant<int, 1>());
-                    else if (fold) __syncthreads();                            // the barrier of the folded projection
-                    __syncthreads();             // every wave has read the field
-                    PH(2);
-                    write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH, (s > 2 && has_aer) ? xdel : nullptr);
-                    __syncthreads();
+                    if constexpr (SPLIT_OK) {
+                        if (split) {
+                            // more row tiles than waves, fewer than two per wave (N = 22 ... 32): one own tile per wave, the
+                            // left-over tiles shared out by (half system, column tile) -- sos_dev.h gemm_source_split
+                            v4d own[2][1][CT], accs[2] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}};
+#pragma unroll
+                            for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                                for (int ct = 0; ct < CT; ct++) own[sy][0][ct] = (v4d){0., 0., 0., 0.};
+                            const int R = cx.rtph - NW;
+                            {
+#define SOS_GEMM_S(RAYV, FOLDV)                                                                                        \
+    gemm_source_split<RAYV, FOLDV, CT, NW, FS, KHM, (SOS_PRECOMBINE_LDS != 0)>(own, accs, R, wv >> 1, wv & 1, mpa, has_aer != 0, vtp, ufp, cx.ks2h, \
+                                                               cx.rtph, bx, xdel, ydel, lane, wv, cx.prow, pcb)
+                                if (s > 2) SOS_GEMM_S(-1, false);
+                                else if (s & 1) { if (fold) SOS_GEMM_S(1, true); else SOS_GEMM_S(1, false); }
+                                else { if (fold) SOS_GEMM_S(0, true); else SOS_GEMM_S(0, false); }
+#undef SOS_GEMM_S
+                            }
+                            __syncthreads();         // every wave has read the field
+                            PH(2);
+                            const double *xd = (s > 2 && has_aer) ? xdel : nullptr;
+                            write_back_source<1, CT, NW, FS, KHM>(own, cbuf, lane, wv, KH, xd);
+                            write_back_shared<FS, KHM>(accs, R, wv >> 1, wv & 1, cbuf, lane, cx.rtph, xd);
+                            __syncthreads();
+                            combine_shared<NW, FS, KHM, CT * 16>(cbuf, t, NTH, cx.rtph);
+                            __syncthreads();
+                        }
+                    }
+                    if (!(SPLIT_OK && split)) {
+                        if (tile_b) contract(std::integral_constant<int, RTWH>());
+                        else if (tile_a) contract(std::integral_constant<int, 1>());
+                        else if (fold) __syncthreads();                        // the barrier of the folded projection
+                        __syncthreads();             // every wave has read the field
+                        PH(2);
+                        write_back_source<RTWH, CT, NW, FS, KHM>(acc, cbuf, lane, wv, KH, (s > 2 && has_aer) ? xdel : nullptr);
+                        __syncthreads();
+                    }
                 }
                 PH(3);
             }
@@ -439,10 +476,23 @@ int sos_os_variant(int n, int nt_max, int *nw, int *rtw, int *ct, size_t *lds_by
 }
 #endif
 
-template <int NW, int RTWH, int CT, bool ZO, bool SURF>
+// five or six row tiles on four waves, and room for the partials in the pad rows of the field (sos_dev.h gemm_source_split)
+static bool sos_split_applies(const SosDev &cx, int nw, int rtw, int ct)
+{
+#ifdef SOS_NO_SPLIT
+    return false;
+#else
+    return nw == 4 && rtw == 2 && ct == 2 && cx.rtph > nw && cx.rtph <= nw + 2 && 16 * cx.rtph + 16 * (cx.rtph - nw) <= sos_khm(nw, rtw);
+#endif
+}
+
+template <int NW, int RTWH, int CT, bool ZO, bool SURF, bool SPLIT = false>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st, int *hip_err)
 {
-    auto kern = k_sos_os<NW, RTWH, CT, ZO, SURF>;
+    if constexpr (!SPLIT && NW == 4 && RTWH == 2 && CT == 2) {
+        if (sos_split_applies(cx, NW, RTWH, CT)) return launch_variant<NW, RTWH, CT, ZO, SURF, true>(cx, bn, lds, st, hip_err);
+    }
+    auto kern = k_sos_os<NW, RTWH, CT, ZO, SURF, SPLIT>;
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif
