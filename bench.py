@@ -233,7 +233,7 @@ def kernel_ms(cx, bins, out, reps=3):
 def pmc_traffic(tag, **match):
     """HBM traffic of one launch: rocprofv3 PMC passes of this same command, summarised (with the gfx950 corrections of
     MI355X_MICROARCH.md) by scripts/summarize_profiles.py into profiles/; None when the workload differs."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_hbm%s.json" % (rnd, tag))) as f:
                 pm = json.load(f)

@@ -6,7 +6,7 @@
 #   4. --pmc MFMA busy counters
 #   5. --kernel-trace --stats of scripts/aux_kernels.py (noyaux, glitter, land, Mie, profile, absprofile, trphi kernels)
 # Outputs land under gpurun_out/prof/<tag>/; scripts/summarize_profiles.py turns them into profiles/<tag>_*.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p $OUT
 REPO=$PWD
@@ -23,4 +23,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ARG
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_r -o write_r -- python3 $ARGR > $OUT/write_r.log 2>&1 && echo write_r done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o mfma -- python3 $ARGS > $OUT/mfma.log 2>&1 && echo mfma done
 rocprofv3 --kernel-trace --stats -d $OUT/aux -o aux -- python3 $REPO/scripts/aux_kernels.py > $OUT/aux.log 2>&1 && echo aux done
+#   6. --kernel-trace --stats of the hyperspectral leg (bench.py --workload hyperspectral: sos_spectrum over 2496 wavelengths)
+rocprofv3 --kernel-trace --stats -d $OUT/hyper -o hyper -- python3 $REPO/bench.py --workload hyperspectral > $OUT/hyper.log 2>&1 && echo hyper done
 find $OUT -name "*.db" | head -20

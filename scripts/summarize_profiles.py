@@ -27,7 +27,7 @@ def rows(db, q):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r03"
     bins = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 32768      # bench.py's default batch
     nt = int(sys.argv[sys.argv.index("--nt") + 1]) if "--nt" in sys.argv else 30
     src = os.path.join(ROOT, "gpurun_out", "prof", tag)
@@ -91,6 +91,16 @@ def main():
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ns", "average_ns", "min_ns", "max_ns"])
             for r in st:
+                w.writerow([r[0], r[1], r[2], "%.1f" % r[3], r[4], r[5]])
+
+    hyp = os.path.join(src, "hyper", "hyper_results.db")
+    if os.path.exists(hyp):
+        st = rows(hyp, "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc")
+        with open(os.path.join(out, "%s_hyperspectral_kernel_stats.csv" % tag), "w", newline="") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload hyperspectral   (run_sos.sos_spectrum, 2496 wavelengths, 5732 CKD bins; durations in ns)\n")
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ns", "average_ns", "min_ns", "max_ns"])
+            for r in st[:40]:
                 w.writerow([r[0], r[1], r[2], "%.1f" % r[3], r[4], r[5]])
 
     db = os.path.join(src, "mfma", "mfma_results.db")
