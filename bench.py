@@ -167,7 +167,7 @@ def _free_port():
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torchrun and relay its exit
     code.  Nothing in this process has touched the GPU yet (no torch import)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % (args.gpus * args.ranks_per_gpu),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -474,7 +474,8 @@ def run_hyperspectral(pkg, torch, dist, world, rank, every=1):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     nmine = max(1, len(kws) // world)
@@ -505,6 +506,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time of the all-cores CPU baseline")
     ap.add_argument("--no-hyper", action="store_true", help="skip the appended hyperspectral measurement (N = 1 default run)")
     ap.add_argument("--spectrum-every", type=int, default=1, help="hyperspectral: take every k-th spectral interval")
+    ap.add_argument("--ranks-per-gpu", type=int, default=1,
+                    help="hyperspectral only: host processes (ranks) sharing each GPU -- the wavelength partition is the same as "
+                         "over GPUs, the host preparation (Python, one interpreter per rank) runs in parallel; gloo gather")
     ap.add_argument("--cpu-sample", type=int, default=224, help="bins timed on the CPU baseline (about 15 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mix", action="store_true", help="skip the appended realistic_mix measurement (N = 1 default run)")
@@ -515,13 +519,16 @@ def main():
     if args.cpu_worker >= 0:
         cpu_worker(args)
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    rpg = max(1, args.ranks_per_gpu)
+    if rpg > 1 and args.workload != "hyperspectral":
+        sys.exit("bench.py: --ranks-per-gpu is for --workload hyperspectral (the bin-sharded workloads fill a GPU from one rank)")
+    if args.gpus * rpg > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    local = int(os.environ.get("LOCAL_RANK", "0")) // rpg
+    if world != args.gpus * rpg:
+        sys.exit("bench.py: --gpus %d x --ranks-per-gpu %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, rpg, world))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if args.dry_run:
@@ -538,11 +545,12 @@ def main():
     S = pkg.synth
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # several ranks on one GPU: RCCL refuses duplicate devices, and the wavelength partition only gathers host objects
+        dist.init_process_group("gloo" if rpg > 1 else "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
-    base = dict(metric="CKD spectral bins/sec (full Stokes I,Q,U, TOA+surface)", unit="bins/s", n_gpus=world,
+    base = dict(metric="CKD spectral bins/sec (full Stokes I,Q,U, TOA+surface)", unit="bins/s", n_gpus=args.gpus,
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic")
 
     if args.workload == "realistic":
@@ -557,6 +565,8 @@ def main():
         return
     if args.workload == "hyperspectral":
         r = run_hyperspectral(pkg, torch, dist, world, rank, args.spectrum_every)
+        if rpg > 1:
+            r["host_processes_per_gpu"] = rpg
         if rank == 0:
             print(json.dumps(dict(base, scaling="strong", steps=1, warmup=1, ms_per_step=1e3 * r["seconds"], **r)))
         if world > 1:
