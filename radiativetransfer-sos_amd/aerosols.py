@@ -175,20 +175,30 @@ def _legendre_tables(xmu_bytes, os_nb):
         e = math.sqrt(1. * (k + 2.) * (k - 2.)) / (2. * k + 1.)
         pol[k + 1] = d * (xr * pol[k] - e * pol[k - 1])
     f = np.float32
-    coefs = []
-    for i in range(2, os_nb + 1):               # CO1, CO2, X2 are REAL*4 expressions
-        co1 = float(f(4) * (f(2 * i) + f(1.)) / f(i) / (f(i) - f(1.)) / (f(i) + f(1.)) / (f(i) + f(2.)))
-        co2 = float(f(i) * (f(i) - f(1.)) / ((f(i) + f(1.)) * (f(i) + f(2.))))
+    # per order I = 2 .. os_nb: CO1, CO2 and the X2 weights of the four sums, as zero-padded matrices [os_nb - 1][os_nb // 2 + 1]
+    # with the indices they multiply (a padded entry has weight 0 and comes LAST in its row: a sequential sum over the padded row
+    # equals the Fortran loop's sum exactly, x + 0.0 = x)
+    ni, wmax = os_nb - 1, os_nb // 2 + 1
+    co1, co2 = np.zeros(ni), np.zeros(ni)
+    xn, xm = np.zeros((ni, wmax)), np.zeros((ni, wmax))
+    jn_idx, jm_idx = np.zeros((ni, wmax), dtype=np.int64), np.zeros((ni, wmax), dtype=np.int64)
+    for r, i in enumerate(range(2, os_nb + 1)):               # CO1, CO2, X2 are REAL*4 expressions
+        co1[r] = float(f(4) * (f(2 * i) + f(1.)) / f(i) / (f(i) - f(1.)) / (f(i) + f(1.)) / (f(i) + f(2.)))
+        co2[r] = float(f(i) * (f(i) - f(1.)) / ((f(i) + f(1.)) * (f(i) + f(2.))))
         nn, mm = int(i * .5), int((i - 1) * .5)
         fi1 = (f(i) - f(1.)) * (f(i) - f(1.))
         jn = np.arange(1, nn + 1)
-        x2n = (fi1 - f(3.) * ((2 * jn).astype(np.float32) - f(1.)) * (i - jn).astype(np.float32)).astype(np.float64)
+        xn[r, :nn] = (fi1 - f(3.) * ((2 * jn).astype(np.float32) - f(1.)) * (i - jn).astype(np.float32)).astype(np.float64)
+        jn_idx[r, :nn] = i - 2 * jn
         jm = np.arange(0, mm + 1)
-        x2m = (fi1 - f(3.) * jm.astype(np.float32) * ((2 * i - 2 * jm).astype(np.float32) - f(1.))).astype(np.float64)
-        coefs.append((co1, co2, i - 2 * jn, x2n, i - 2 * jm - 1, x2m))
+        xm[r, :mm + 1] = (fi1 - f(3.) * jm.astype(np.float32) * ((2 * i - 2 * jm).astype(np.float32) - f(1.))).astype(np.float64)
+        jm_idx[r, :mm + 1] = i - 2 * jm - 1
+    coefs = (co1, co2, xn, jn_idx, xm, jm_idx)
+    for a in coefs:
+        a.setflags(write=False)
     for a in (sel, xr, pl, pol):
         a.setflags(write=False)
-    return sel, xr, pl, pol, tuple(coefs)
+    return sel, xr, pl, pol, coefs
 
 
 def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
@@ -232,18 +242,17 @@ def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
     beta22 = beta22 * (2. * kk + 1.) * .5
     delta33 = delta33 * (2. * kk + 1.) * .5
     gamma12 = gamma12 * (2. * kk + 1.) * .5
+    # alpha_I, zeta_I for all orders at once: the four sums of every order run along the rows of the padded weight matrices,
+    # sequentially (cumsum), exactly as the Fortran loops J = 1..NN / J = 0..MM add them
+    co1, co2r, xn, jn_idx, xm, jm_idx = coefs
+    last = lambda a: np.cumsum(a, axis=1)[:, -1]
+    s1, s2 = last(xn * beta22[jn_idx]), last(xn * delta33[jn_idx])
+    s3, s4 = last(xm * beta22[jm_idx]), last(xm * delta33[jm_idx])
     alp, zeta = np.zeros(os_nb + 1), np.zeros(os_nb + 1)
-    for i, (co1, co2r, jn_idx, x2n, jm_idx, x2m) in enumerate(coefs, start=2):
-        co3 = co2r * delta33[i]
-        co2 = co2r * beta22[i]
-        s1 = s2 = 0.
-        if len(jn_idx):
-            s1 = float(_seq_sum(x2n * beta22[jn_idx]))
-            s2 = float(_seq_sum(x2n * delta33[jn_idx]))
-        s3 = float(_seq_sum(x2m * beta22[jm_idx]))
-        s4 = float(_seq_sum(x2m * delta33[jm_idx]))
-        zeta[i] = co3 - co1 * (s2 - s3)
-        alp[i] = co2 - co1 * (s1 - s4)
+    co3 = co2r * delta33[2:]
+    co2 = co2r * beta22[2:]
+    zeta[2:] = co3 - co1 * (s2 - s3)
+    alp[2:] = co2 - co1 * (s1 - s4)
     z1 = beta11[0]
     return dict(alpha=alp / z1, beta=beta11 / z1, gamma=gamma12 / z1, zeta=zeta / z1, beta22=beta22 / z1, delta33=delta33 / z1,
                 coef_tronca=float(coef), itronc=itronc)

@@ -741,12 +741,12 @@ def _trphi_pack(n, mu, out, rows, phi_fin):
     theta_fin = np.zeros(81)
     theta_fin[:n] = np.degrees(np.arccos(mu))
     names = ["i", "q", "u", "sca", "ang", "rate", "lpol"]       # order of sosgpu_trphi's 7 output rows
-    tabs = {k: np.zeros((361, 81)) for k in names}
-    tabs_dn = {k: np.zeros((361, 81)) for k in names}
+    block = np.zeros((2, 7, 361, 81))                           # the fourteen tables in one allocation
     nr = len(rows)
-    for qi, nm in enumerate(names):
-        tabs[nm][rows, :n] = out[:nr, qi, n + 1:]               # up-going jj = 1..N
-        tabs_dn[nm][rows, :n] = out[:nr, qi, :n][:, ::-1]       # down-going jj = -1..-N
+    block[0][:, rows, :n] = out[:nr, :, n + 1:].transpose(1, 0, 2)            # up-going jj = 1..N
+    block[1][:, rows, :n] = out[:nr, :, :n][:, :, ::-1].transpose(1, 0, 2)    # down-going jj = -1..-N
+    tabs = {nm: block[0, qi] for qi, nm in enumerate(names)}
+    tabs_dn = {nm: block[1, qi] for qi, nm in enumerate(names)}
     return phi_fin, theta_fin, tabs, tabs_dn
 
 
