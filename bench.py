@@ -519,6 +519,9 @@ def main():
     if args.cpu_worker >= 0:
         cpu_worker(args)
         return
+    # sos_spectrum spreads the per-wavelength preparation kernels over HIP streams: give them hardware queues of their own (the
+    # runtime's default is 4; must be set before the first GPU call of the process)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     rpg = max(1, args.ranks_per_gpu)
     if rpg > 1 and args.workload != "hyperspectral":
         sys.exit("bench.py: --ranks-per-gpu is for --workload hyperspectral (the bin-sharded workloads fill a GPU from one rank)")

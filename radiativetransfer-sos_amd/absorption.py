@@ -106,8 +106,9 @@ def ckd_file_name(nabs, nu, nustep):
 def read_ckd_coeff(nabs, nu, nustep, root=None):
     """READ_CKD_COEFF for gas nabs (1-based): dict(numax, numin, tab_temp, tab_pres, tab_conc (H2O), nexp[nwa],
     ai[nwa][5], ki[nwa][5][NP][NT] (H2O: [nwa][5][NC][NP][NT])).  List-directed reads: one record per READ.
-    A file holds 50 spectral intervals (the H2O ones take 0.25 s to parse): parsed files are kept (the last 32, keyed by
-    path, size and modification time), so a hyperspectral loop re-reads nothing while it stays inside a file."""
+    A file holds 50 spectral intervals (the H2O ones take 0.25 s to parse): parsed files are kept (the last 512 -- a whole
+    spectrum of the 10 cm-1 tables is 400 files, about 0.5 GB parsed --, keyed by path, size and modification time), so a
+    hyperspectral loop re-reads nothing."""
     if nustep not in (1, 5, 10):
         raise AbsorptionError("The required spectral resolution is not supported : %g cm-1" % nustep)
     rel, numax_f, numin_f = ckd_file_name(nabs, nu, nustep)
@@ -119,7 +120,7 @@ def read_ckd_coeff(nabs, nu, nustep, root=None):
     return _read_ckd_file(path, nabs, nustep, numax_f, numin_f, st.st_size, st.st_mtime_ns)
 
 
-@functools.lru_cache(maxsize=32)
+@functools.lru_cache(maxsize=512)
 def _read_ckd_file(path, nabs, nustep, numax_f, numin_f, _size, _mtime):
     try:
         with open(path) as f:
@@ -159,7 +160,13 @@ def _read_ckd_file(path, nabs, nustep, numax_f, numin_f, _size, _mtime):
         nexp[iwa] = nmax
         ai[iwa, :nmax] = [float(v) for v in rec(nmax)[:nmax]]
         nrow = nmax * nc * npr
-        blk = np.array([[float(v) for v in lines[pos + r].split()[lead:lead + nt]] for r in range(nrow)])
+        # (one conversion for the whole block: rows of `lead` indices + nt coefficients; a row of another shape -- never seen
+        #  in the reference's tables -- falls back to the per-row form)
+        flat = np.array(" ".join(lines[pos:pos + nrow]).split(), dtype=np.float64)
+        if flat.size == nrow * (lead + nt):
+            blk = flat.reshape(nrow, lead + nt)[:, lead:]
+        else:
+            blk = np.array([[float(v) for v in lines[pos + r].split()[lead:lead + nt]] for r in range(nrow)])
         pos += nrow
         ki[iwa, :nmax] = blk.reshape(nmax, nc, npr, nt)
     if nabs != 1:
