@@ -59,10 +59,20 @@ constexpr int COLS = SOS_STREAM_COLS;      // levels per chunk (two 16-column MF
 constexpr int VPAD = 8;       // level vectors are stored with a +1 offset (entry e = level e-1) and a few spare entries
 }
 
+// Row capacity of the field layout.  Round 2 sized it by the wave shape alone, KHM = 16 NW RTWH rows per half: 64, 128, 256.  A half
+// system of 66 ... 96 rows (N = 22 ... 32 -- the reference's default of 24 Gauss angles is N = 25) then moved 128-row chunks through
+// LDS and HBM: N = 22 ran 32 % slower than N = 21 for 5 % more work (profiles/r03_n_sweep.txt).  The layout is now sized in row
+// tiles, KHT = 5 or 6 for those direction counts (KHM = 80 / 96, FS = 162 / 194: 41 / 50 KB chunks instead of 66 KB), the wave
+// shape staying <4,2> (wave 0, or waves 0 and 1, carry a second tile).  KHM = 16 KHT, FS = 2 KHM + 2 (still = 2 mod 4 doubles:
+// conflict-free ds_read_b128 of the B operands), NS = directions capacity.
+__host__ __device__ constexpr int skhm(int kht) { return 16 * kht; }
+__host__ __device__ constexpr int sfs(int kht) { return 2 * skhm(kht) + 2; }
+__host__ __device__ constexpr int sns(int kht) { return (skhm(kht) / 3 + 1) & ~1; }
+
 // scratch of one bin, in doubles (lpb = level capacity, a multiple of COLS)
-__host__ __device__ inline size_t stream_scratch_doubles(int nw, int rtw, int lpb)
+__host__ __device__ inline size_t stream_scratch_doubles(int nw, int kht, int lpb)
 {
-    const size_t fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw), khm = sos_khm(nw, rtw), nch = lpb / COLS;
+    const size_t fs = sfs(kht), ns = sns(kht), khm = skhm(kht), nch = lpb / COLS;
     const size_t d = (size_t)lpb * fs + (size_t)(lpb + 1) * ns + 7 * (size_t)(lpb + VPAD) + nch * (2 * khm + 2 * ns) +
                      2 * 64 * (size_t)nw + 8;                  // + state carried from one launch to the next (i4, i5 per thread)
     return (d + 15) & ~(size_t)15;
@@ -121,7 +131,7 @@ __device__ __forceinline__ void glds_copy(const double *g, double *l, int units,
                                          (__attribute__((address_space(3))) void *)(unsigned long)(lb + (unsigned)full * (NTH * 16)), 16, 0, AUX);
 }
 
-template <int NW, int RTWH, bool ZO, bool SURF, bool PERSIST>
+template <int NW, int RTWH, bool ZO, bool SURF, bool PERSIST, int KHT = NW * RTWH>
 __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void k_sos_stream(const SosDev cx_arg, const SosBins bn)
 {
     SOS_BIND_CTX(cx, cx_arg, bn);
@@ -129,7 +139,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
     const SosBins &bn_kernel = bn;
     extern __shared__ double smem[];
     constexpr int CT = COLS / 16, NTH = 64 * NW, HW = NW / 2;
-    constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
+    static_assert(KHT > NW * (RTWH - 1) && KHT <= NW * RTWH, "layout rows: more than RTWH - 1 tiles per wave, at most RTWH");
+    constexpr int KHM = skhm(KHT), FS = sfs(KHT), NS = sns(KHT);
     constexpr int VL = COLS + VPAD;        // chunk copy of a level vector: entry e = level (layer) l0 - 1 + e
     const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
     const int LPB = bn.lpb, NCH = LPB / COLS, VS = LPB + VPAD;
@@ -809,11 +820,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
 // Order-parallel form, second half: the Fourier stop test (SOS_ARRET_FOURIER, SOS_OS.F:3709; accumulation :1460-1473, exit
 // :1585) of orders [s0, s1) of every bin, replayed in sequence from the I3 terms the order tasks left in bn.spec_i3 -- the same
 // statements as at the end of run_task's order loop, with the same thread -> row mapping.  One workgroup per bin.
-template <int NW, int RTWH>
+template <int NW, int KHT>
 __global__ __launch_bounds__(64 * NW) void k_sos_stream_replay(const SosDev cx, const SosBins bn, int s0, int s1)
 {
     __shared__ int red[2 * NW];
-    constexpr int NTH = 64 * NW, HW = NW / 2, KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
+    constexpr int NTH = 64 * NW, HW = NW / 2, KHM = skhm(KHT), FS = sfs(KHT), NS = sns(KHT);
     const int LPB = bn.lpb, NCH = LPB / COLS, VS = LPB + VPAD, N = cx.n, S1 = cx.smax + 1;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     if (uniform_i32(bn.norders[b]) < 0) return;                     // malformed bin (flagged by the set-up launch)
@@ -853,44 +864,56 @@ __global__ __launch_bounds__(64 * NW) void k_sos_stream_replay(const SosDev cx, 
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t stream_lds_bytes(int nw, int rtw)
+static size_t stream_lds_bytes(int kht)
 {
-    const int fs = sos_fs(nw, rtw), ns = sos_ns(nw, rtw);
+    const int fs = sfs(kht), ns = sns(kht);
     return ((size_t)COLS * fs + 3 * ns + 2 + 2 * ns + 16 + 2 * ns + (size_t)COLS * ns + 7 * (COLS + VPAD)) * sizeof(double);
 }
 
-static void stream_shape(int n, int *nw, int *rtw)
+// waves, row tiles per wave, row tiles of the layout for N directions
+static void stream_shape(int n, int *nw, int *rtw, int *kht)
 {
     const int kh = sos_round_up(3 * n, 8);
-    if (kh > 128) { *nw = 8; *rtw = 2; }
-    else { *nw = 4; *rtw = kh <= 64 ? 1 : 2; }
+    if (kh > 128) { *nw = 8; *rtw = 2; *kht = 16; }
+    else if (kh <= 64) { *nw = 4; *rtw = 1; *kht = 4; }
+    else {
+        *nw = 4; *rtw = 2;
+        *kht = kh <= 80 ? 5 : kh <= 96 ? 6 : 8;
+#ifdef SOS_STREAM_WIDE
+        *kht = 8;                                          // round 2's layout (A/B measurements)
+#endif
+        // the persistent, order-scheduled form (opt-in) exists for the full-width layout only
+        if (const char *e = getenv("SOSGPU_STREAM_PERSIST")) { if (atoi(e) != 0) *kht = 8; }
+    }
 }
 
 #ifndef SOS_MULTI
 size_t sos_stream_scratch_doubles(int n, int lpb)
 {
-    int nw, rtw;
-    stream_shape(n, &nw, &rtw);
-    return stream_scratch_doubles(nw, rtw, lpb);
+    int nw, rtw, kht;
+    stream_shape(n, &nw, &rtw, &kht);
+    return stream_scratch_doubles(nw, kht, lpb);
 }
 #endif
 
-template <int NW, int RTWH, bool ZO, bool SURF>
+template <int NW, int RTWH, bool ZO, bool SURF, int KHT = NW * RTWH>
 static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_t st, int *hip_err)
 {
 #ifdef SOS_MULTI
     const bool persist = false;                            // (the per-bin context is bound to blockIdx.x)
     if (bn.queue) return SOSGPU_E_UNSUPPORTED;
-    auto kern = k_sos_stream<NW, RTWH, ZO, SURF, false>;
+    auto kern = k_sos_stream<NW, RTWH, ZO, SURF, false, KHT>;
 #else
     const bool persist = bn.queue != nullptr;
-    auto kern = persist ? k_sos_stream<NW, RTWH, ZO, SURF, true> : k_sos_stream<NW, RTWH, ZO, SURF, false>;
+    if (persist && KHT != NW * RTWH) return SOSGPU_E_UNSUPPORTED;       // (stream_shape keeps the full width for that form)
+    auto kern = k_sos_stream<NW, RTWH, ZO, SURF, false, KHT>;
+    if constexpr (KHT == NW * RTWH) { if (persist) kern = k_sos_stream<NW, RTWH, ZO, SURF, true, KHT>; }
 #endif
-    const size_t lds = stream_lds_bytes(NW, RTWH);
+    const size_t lds = stream_lds_bytes(KHT);
     // the dynamic-LDS limit of a kernel is set once per device and size (the call costs tens of microseconds: with few bins per
     // wavelength the host launch path is what bounds a hyperspectral loop, scripts/spectrum_bench.py)
     // (atomics: host threads of run_sos.sos_proc_many launch concurrently; a lost update only repeats the call)
-    static std::atomic<size_t> configured[2][16];
+    static std::atomic<size_t> configured[2][16];           // (per instantiation of this function: one per kernel variant)
     static std::atomic<int> cus[16];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -921,18 +944,20 @@ static int launch_stream_variant(const SosDev &cx, const SosBins &bn, hipStream_
 #ifndef SOS_MULTI
 int sos_stream_threads(int n)
 {
-    int nw, rtw;
-    stream_shape(n, &nw, &rtw);
+    int nw, rtw, kht;
+    stream_shape(n, &nw, &rtw, &kht);
     return 64 * nw;
 }
 
 int launch_sos_stream_replay(const SosDev &cx, const SosBins &bn, int s0, int s1, hipStream_t st, int *hip_err)
 {
-    int nw, rtw;
-    stream_shape(cx.n, &nw, &rtw);
-    if (nw == 4 && rtw == 1) k_sos_stream_replay<4, 1><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
-    else if (nw == 4) k_sos_stream_replay<4, 2><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
-    else k_sos_stream_replay<8, 2><<<bn.nb, 512, 0, st>>>(cx, bn, s0, s1);
+    int nw, rtw, kht;
+    stream_shape(cx.n, &nw, &rtw, &kht);
+    if (kht == 4) k_sos_stream_replay<4, 4><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
+    else if (kht == 5) k_sos_stream_replay<4, 5><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
+    else if (kht == 6) k_sos_stream_replay<4, 6><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
+    else if (kht == 8) k_sos_stream_replay<4, 8><<<bn.nb, 256, 0, st>>>(cx, bn, s0, s1);
+    else k_sos_stream_replay<8, 16><<<bn.nb, 512, 0, st>>>(cx, bn, s0, s1);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return -2; }
     return 0;
@@ -942,21 +967,21 @@ int launch_sos_stream_replay(const SosDev &cx, const SosBins &bn, int s0, int s1
 int launch_sos_stream(const SosDev &cx, const SosBins &bn, int nt_max, hipStream_t st, int *hip_err)
 {
     if (cx.n < 1 || cx.n > 85 || nt_max < 1 || nt_max > 1023) return SOSGPU_E_UNSUPPORTED;
-    int nw, rtw;
-    stream_shape(cx.n, &nw, &rtw);
-    if (cx.kh > sos_khm(nw, rtw) || cx.rtph * 16 < cx.kh) return SOSGPU_E_UNSUPPORTED;
-    if (!bn.scratch || bn.lpb < nt_max + 1 || bn.lpb % COLS || bn.scr_stride < stream_scratch_doubles(nw, rtw, bn.lpb))
+    int nw, rtw, kht;
+    stream_shape(cx.n, &nw, &rtw, &kht);
+    if (cx.kh > skhm(kht) || cx.rtph * 16 < cx.kh || cx.rtph > kht) return SOSGPU_E_UNSUPPORTED;
+    if (!bn.scratch || bn.lpb < nt_max + 1 || bn.lpb % COLS || bn.scr_stride < stream_scratch_doubles(nw, kht, bn.lpb))
         return SOSGPU_E_UNSUPPORTED;
     const int zo = bn.jout != nullptr;
-#define V(NWV, R)                                                                              \
-    if (nw == NWV && rtw == R) {                                                               \
+#define V(NWV, R, K)                                                                           \
+    if (nw == NWV && rtw == R && kht == K) {                                                   \
         if (cx.imat_surf)                                                                      \
-            return zo ? launch_stream_variant<NWV, R, true, true>(cx, bn, st, hip_err)         \
-                      : launch_stream_variant<NWV, R, false, true>(cx, bn, st, hip_err);       \
-        return zo ? launch_stream_variant<NWV, R, true, false>(cx, bn, st, hip_err)            \
-                  : launch_stream_variant<NWV, R, false, false>(cx, bn, st, hip_err);          \
+            return zo ? launch_stream_variant<NWV, R, true, true, K>(cx, bn, st, hip_err)      \
+                      : launch_stream_variant<NWV, R, false, true, K>(cx, bn, st, hip_err);    \
+        return zo ? launch_stream_variant<NWV, R, true, false, K>(cx, bn, st, hip_err)         \
+                  : launch_stream_variant<NWV, R, false, false, K>(cx, bn, st, hip_err);       \
     }
-    V(4, 1) V(4, 2) V(8, 2)
+    V(4, 1, 4) V(4, 2, 5) V(4, 2, 6) V(4, 2, 8) V(8, 2, 16)
 #undef V
     return SOSGPU_E_UNSUPPORTED;
 }
