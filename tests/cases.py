@@ -68,6 +68,15 @@ def make_case(name):
     elif name == "aer_n9_nt600":          # CTE_OS_NT = 600 (SOS.h:202)
         ng, nt, os_nb, g, kabs = 8, 600, 16, 0.5, [1.0]
         kw = dict(ro=0.1)
+    elif name == "brdf_zout_n30_nt110":   # streamed field of six row tiles per half (N = 27 ... 32)
+        ng, nt, os_nb, g, kabs = 29, 110, 48, 0.7, [0.2]
+        kw = dict(ro=0.02, imat_surf=1, zout=1.2)
+    elif name == "aer_n32_nt75":          # ... at its last direction count (96 rows)
+        ng, nt, os_nb, g, kabs = 31, 75, 48, 0.75, [0.0, 1.0]
+        kw = dict(ro=0.1)
+    elif name == "aer_n26_nt90":          # five row tiles per half at its last direction count (78 rows)
+        ng, nt, os_nb, g, kabs = 25, 90, 48, 0.75, [0.6]
+        kw = dict(ro=0.1)
     elif name == "aer_n21":               # NW=4, one row tile per wave
         ng, nt, os_nb, g, kabs = 20, 28, 40, 0.7, [0.0, 1.5]
         kw = dict(ro=0.15)
@@ -125,7 +134,8 @@ def make_case(name):
 ALL_CASES = ["rayleigh_n25", "aer_n41", "aer_n41_g09", "fresnel_n41", "nopolar_n41", "zout_n25_nt60",
              "brdf_n13", "brdf_zout_n13", "black_n9", "igmax_n9",
              "rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600",
-             "aer_n21", "zout_n21_nt50", "aer_n49", "fresnel_n80_nt24", "zout_n65_nt45", "user_angles_n28"]
+             "aer_n21", "zout_n21_nt50", "aer_n49", "fresnel_n80_nt24", "zout_n65_nt45", "user_angles_n28",
+             "brdf_zout_n30_nt110", "aer_n32_nt75", "aer_n26_nt90"]
 
 
 def run_cpu(mod, case, b):

@@ -325,7 +325,8 @@ def test_context_table_rejects_mismatched_contexts(gpu_pkg):
         cx.close()
 
 
-STREAM_CASES = ["rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600"]
+STREAM_CASES = ["rayleigh_n25_nt101", "aer_n41_nt120", "fresnel_zout_n25_nt70", "brdf_n13_nt97", "aer_n9_nt600",
+                "brdf_zout_n30_nt110", "aer_n32_nt75", "aer_n26_nt90"]
 
 
 @pytest.mark.parametrize("mode", ["one_workgroup_per_bin", "persistent_order_scheduled", "one_order_per_launch", "three_orders_per_launch"])
@@ -382,9 +383,9 @@ def test_streamed_persistent_many_bins_bitwise_equal_to_per_bin_launch(gpu_pkg, 
     cx.close()
 
 
-# every (NW, RTWH, ZO, SURF) instantiation of k_sos_stream -- N = 13: <4,1>, N = 25: <4,2>, N = 49: <8,2> -- with K forced so that
+# every (NW, RTWH, KHT, ZO, SURF) instantiation of k_sos_stream -- N = 13: <4,1,4>, 25: <4,2,5>, 30: <4,2,6>, 41: <4,2,8>, 49: <8,2,16> -- with K forced so that
 # a bin needs several rounds of order tasks + replay (the hand-over of the I3 terms must be checked in every variant)
-_ALL_VARIANTS = [(3, n, 24, surf, zout, 4) for n in (13, 25, 49) for surf in (False, True) for zout in (False, True)]
+_ALL_VARIANTS = [(3, n, 24, surf, zout, 4) for n in (13, 25, 30, 41, 49) for surf in (False, True) for zout in (False, True)]
 
 
 @pytest.mark.parametrize("nb,n,os_nb,surf,zout,k", [(1, 13, 24, False, False, 0), (37, 13, 24, False, False, 0),
