@@ -305,6 +305,23 @@ int  sosgpu_mie(int device, int nbmu, const double *xmu, double rn, double in, i
 int  sosgpu_granu(int device, int nbmu, int nalpha, const float *d_rec, int igranu, double v1, double v2, double v3,
                   double wa, double alphaf, double *out, void *stream);
 
+/* The same integral for `count` (records, distribution, wavelength) jobs at once, ASYNCHRONOUS on `stream` (the wavelengths of
+ * a spectrum: run_sos.sos_spectrum queues the integrals of a batch of wavelengths ahead of their host preparation and fetches
+ * all results with one copy).  One workgroup per job, SOSGPU_GRANU_JOBS_PER_LAUNCH jobs per launch; a job's sums are those of
+ * sosgpu_granu bit for bit (the same code per workgroup).
+ *   jobs[count] (HOST; read before the call returns)   one sosgpu_granu argument set each, all with the same nbmu
+ *   d_out[count][3 + 3 (2 nbmu + 1)] (DEVICE)          the `out` block of sosgpu_granu per job
+ *   d_work[count][work_stride] (DEVICE)                work_stride >= 3 max(nalpha) + 1 doubles; free after `stream` passed the call
+ * Errors: SOSGPU_E_ARG for a malformed job (nothing is launched), SOSGPU_E_HIP. */
+#define SOSGPU_GRANU_JOBS_PER_LAUNCH 32
+typedef struct sosgpu_granu_job {
+    const float *d_rec;                 /* records of sosgpu_mie (device) */
+    int32_t nalpha, igranu;
+    double v1, v2, v3, wa, alphaf;
+} sosgpu_granu_job;
+int  sosgpu_granu_batch(int device, int nbmu, int count, const sosgpu_granu_job *jobs, double *d_out, double *d_work,
+                        size_t work_stride, void *stream);
+
 /* Diagnostic hook: hand the context a device buffer [nb][8] of uint64 that builds compiled with
  * -DSOS_PROFILE_PHASES fill with per-phase cycle sums of the solver kernel (0 order-1 fill, 1 formal solution,
  * 2 contraction, 3 write-back, 4 stop tests, 5 ground boundary, 6 Fourier bookkeeping).  NULL disables.

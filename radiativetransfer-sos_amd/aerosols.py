@@ -15,6 +15,7 @@ functions, 5 user mixture of log-normal / Junge modes.
 
 REAL*4 variables and literals of the Fortran are kept REAL*4 (`np.float32`) where they decide a value."""
 import collections
+import contextlib
 import ctypes as C
 import functools
 import math
@@ -128,16 +129,113 @@ def mie_records(xmu, rn, in_, alphao, alphaf, device=0):
                 qmie=r[:, 4 + w:4 + 2 * w].copy(), umie=r[:, 4 + 2 * w:4 + 3 * w].copy(), alphaf=float(alphaf))
 
 
+# ---- size integrals queued ahead of their use (run_sos.sos_spectrum) ------------------------------------------------------
+# A spectrum needs one or two size integrals per wavelength, each a 0.1 ms device job whose result the host's Legendre
+# expansion waits for.  sos_spectrum therefore runs the aerosol model of a batch of wavelengths once in COLLECT mode (the model
+# code below records the arguments of its size_integral calls and stops before the expansion), queues all of them with
+# sosgpu_granu_batch -- one workgroup per integral, results copied to pinned host memory behind them -- and the real pass finds
+# its integrals ready: one wait per batch instead of one per wavelength.  State is per thread.
+_TLS = threading.local()
+
+
+def _granu_key(xmu, rn, in_, alphaf, igranu, v1, v2, v3, wa, device):
+    return (np.ascontiguousarray(xmu, dtype=np.float64).tobytes(), float(rn), float(in_), float(alphaf), int(igranu), float(v1),
+            float(v2), float(v3), float(wa), int(device))
+
+
+class _GranuBatch:
+    """The results of one sosgpu_granu_batch call on their way to the host (the first reader waits for the copy)."""
+
+    def __init__(self, host, event, keep):
+        self.host, self.event, self.keep = host, event, keep
+
+    def row(self, i):
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = self.keep = None                  # (device output, work area and the records' references)
+        return self.host[i]
+
+
+@contextlib.contextmanager
+def collect_size_integrals():
+    """COLLECT mode: size_integral records its arguments in the yielded list and returns placeholders; aerosols() returns None."""
+    prev = getattr(_TLS, "collect", None)
+    _TLS.collect = reqs = []
+    try:
+        yield reqs
+    finally:
+        _TLS.collect = prev
+
+
+def prefetch_size_integrals(requests, batch=32):
+    """Queue the size integrals `requests` (keys recorded by collect_size_integrals) on the current HIP stream; size_integral
+    calls of this thread with the same arguments then take their result from the batch.  Returns the number queued."""
+    import torch
+    ready = getattr(_TLS, "ready", None)
+    if ready is None:
+        ready = _TLS.ready = {}
+    todo = collections.OrderedDict()
+    for k in requests:
+        if k not in ready and k[4] in (1, 2):
+            todo.setdefault((k[0], k[9]), collections.OrderedDict())[k] = None
+    queued = 0
+    for (xb, device), keys in todo.items():
+        keys = list(keys)
+        xmu = np.frombuffer(xb, dtype=np.float64)
+        w = len(xmu)
+        dev = torch.device("cuda", device)
+        for c0 in range(0, len(keys), batch):
+            part = keys[c0:c0 + batch]
+            jobs = (capi.GranuJob * len(part))()
+            recs = []
+            for j, k in enumerate(part):
+                rec, _ = _mie_device_records(xmu, k[1], k[2], MIE_ALPHAMIN, k[3], device)
+                recs.append(rec)
+                jobs[j] = capi.GranuJob(rec.data_ptr(), int(rec.shape[0]), k[4], k[5], k[6], k[7], k[8], k[3])
+            stride = 3 * max(int(r.shape[0]) for r in recs) + 1
+            out = torch.empty((len(part), 3 + 3 * w), dtype=torch.float64, device=dev)
+            work = torch.empty((len(part), stride), dtype=torch.float64, device=dev)
+            st = torch.cuda.current_stream(dev)
+            capi.check(capi.lib().sosgpu_granu_batch(device, (w - 1) // 2, len(part), jobs, C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(work.data_ptr()), stride, C.c_void_p(st.cuda_stream)),
+                       "sosgpu_granu_batch")
+            host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            b = _GranuBatch(host.numpy(), ev, (out, work, recs, host))
+            for j, k in enumerate(part):
+                ready[k] = (b, j)
+            queued += len(part)
+    return queued
+
+
+def drop_prefetched_size_integrals():
+    _TLS.ready = None
+
+
 def size_integral(xmu, rn, in_, alphaf, igranu, v1, v2, v3, wa, device=0):
     """SOS_MIE + SOS_GRANU for one aerosol mode, both on the GPU: Mie records on the grid alpha_grid(MIE_ALPHAMIN, alphaf)
     (sosgpu_mie; kept on the device and shared by the wavelengths of a spectrum, like the reference's MIE files) integrated
     over the size distribution in record order (sosgpu_granu; igranu 1: log-normal, modal radius v1, ln-std v2; 2: Junge,
     r0 = v1, slope v2, rmax = v3).  Returns kmat1, kmat2 (per particle), somme_nr, p11, p12, p33 [2N+1]."""
     import torch
+    w = len(xmu)
+    coll = getattr(_TLS, "collect", None)
+    ready = getattr(_TLS, "ready", None)
+    if coll is not None or ready:
+        key = _granu_key(xmu, rn, in_, alphaf, igranu, v1, v2, v3, wa, device)
+        if coll is not None:
+            coll.append(key)
+            o = np.ones(w)
+            return 1.0, 1.0, 1.0, o, o.copy(), o.copy()
+        hit = ready.get(key)
+        if hit is not None:
+            out = hit[0].row(hit[1])
+            return float(out[0]), float(out[1]), float(out[2]), out[3:3 + w].copy(), out[3 + w:3 + 2 * w].copy(), out[3 + 2 * w:].copy()
     if igranu not in (1, 2):
         raise AerosolError("unknown size distribution %d" % igranu)
     rec, _ = _mie_device_records(xmu, rn, in_, MIE_ALPHAMIN, alphaf, device)
-    w = len(xmu)
     out = np.zeros(3 + 3 * w)
     st = C.c_void_p(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
     capi.check(capi.lib().sosgpu_granu(device, (w - 1) // 2, int(rec.shape[0]), C.c_void_p(rec.data_ptr()), int(igranu), float(v1),
@@ -624,6 +722,8 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
         kmat1, kmat2, p11, p12, p33 = _user_mixture(p, wa, xmu, device)
     else:
         raise AerosolError("-AER.Model must be 0..5")
+    if getattr(_TLS, "collect", None) is not None:      # COLLECT mode: the size integrals asked for are recorded, nothing more
+        return None
     if p22 is None:
         p22 = p11.copy()                                # spherical particles (:1234, :1495, :1688, :2118, :2762)
     d = decompo_legendre(itronc, xmu, xhr, os_nb, p11, p12, p22, p33)

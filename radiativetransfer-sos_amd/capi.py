@@ -18,9 +18,16 @@ EXPORTS = [
     "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
     "sosgpu_debug_phase_buffer", "sosgpu_debug_scratch", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
     "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce", "sosgpu_absprofile", "sosgpu_land_surface", "sosgpu_mie", "sosgpu_granu",
+    "sosgpu_granu_batch",
     "sosgpu_ctx_table_entry_bytes", "sosgpu_ctx_table", "sosgpu_os_solve_multi", "sosgpu_trim",
 ]
 SCAL_BASE = 10          # SOSGPU_SCAL_BASE: scalar block of sosgpu_aggregate = SCAL_BASE + N doubles
+
+
+class GranuJob(C.Structure):
+    """sosgpu_granu_job (include/sosgpu.h)."""
+    _fields_ = [("d_rec", C.c_void_p), ("nalpha", C.c_int32), ("igranu", C.c_int32), ("v1", C.c_double), ("v2", C.c_double),
+                ("v3", C.c_double), ("wa", C.c_double), ("alphaf", C.c_double)]
 
 
 class SosgpuError(RuntimeError):
@@ -108,6 +115,8 @@ def lib():
         L.sosgpu_mie.argtypes = [i32, i32, vp, dbl, dbl, i32, vp, vp, vp, vp]
         L.sosgpu_granu.restype = i32
         L.sosgpu_granu.argtypes = [i32, i32, i32, vp, i32, dbl, dbl, dbl, dbl, dbl, vp, vp]
+        L.sosgpu_granu_batch.restype = i32
+        L.sosgpu_granu_batch.argtypes = [i32, i32, i32, C.POINTER(GranuJob), vp, vp, C.c_size_t, vp]
         L.sosgpu_reduce.restype = i32
         L.sosgpu_reduce.argtypes = [vp, vp, i32, vp, vp]
         L.sosgpu_ctx_bytes.restype = C.c_size_t

@@ -1280,6 +1280,25 @@ extern "C" int sosgpu_granu(int device, int nbmu, int nalpha, const float *d_rec
     return SOSGPU_OK;
 }
 
+extern "C" int sosgpu_granu_batch(int device, int nbmu, int count, const sosgpu_granu_job *jobs, double *d_out, double *d_work,
+                                  size_t work_stride, void *stream)
+{
+    if (nbmu < 1 || nbmu > 100 || count < 0 || (count && (!jobs || !d_out || !d_work))) return SOSGPU_E_ARG;
+    for (int k = 0; k < count; k++) {
+        const sosgpu_granu_job &j = jobs[k];
+        if (j.nalpha < 1 || !j.d_rec || j.igranu < 1 || j.igranu > 2 || !(j.wa > 0.) || work_stride < (size_t)3 * j.nalpha + 1)
+            return SOSGPU_E_ARG;
+    }
+    if (!count) return SOSGPU_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    launch_granu_batch(count, nbmu, jobs, d_work, work_stride, d_out, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return SOSGPU_OK;
+}
+
 // Diagnostic: the streamed solver's scratch of this context (device pointer, size in doubles) and, after an order-parallel
 // solve, where its I3 hand-over block starts (doubles from the start; 0 when the last solve did not use that form).
 extern "C" int sosgpu_debug_scratch(sosgpu_ctx *cx, double **d_scratch, size_t *doubles, size_t *spec_i3_offset)

@@ -1,5 +1,6 @@
 // csrc/kernels.h -- host-side launchers of the gfx950 kernels (internal to libsosgpu.so).
 #pragma once
+#include "../../include/sosgpu.h"
 #include "sos_common.h"
 
 void launch_noyaux(const SosDev &cx, hipStream_t st);
@@ -67,5 +68,8 @@ size_t mie_scratch_doubles(double alpha_max, int count);
 // SOS_GRANU on the device records: d_work[3 na + 1], d_out[3 + 3 (2 nbmu + 1)] (mie.hip)
 void launch_granu(int na, int nbmu, const float *d_rec, int igranu, double v1, double v2, double v3, double wa, double alphaf,
                   double *d_work, double *d_out, hipStream_t st);
+// ... for `count` jobs, one workgroup each: d_work[count][work_stride], d_out[count][3 + 3 (2 nbmu + 1)]
+void launch_granu_batch(int count, int nbmu, const sosgpu_granu_job *jobs, double *d_work, size_t work_stride, double *d_out,
+                        hipStream_t st);
 int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, const double *d_alphas, int n_lds, double alpha_lds,
                double alpha_max, double *d_scratch, float *d_rec, double *d_g, int32_t *d_err, hipStream_t st);

@@ -199,8 +199,8 @@ int launch_mie(int nalpha, int nbmu, const double *d_xmu, double rn, double in, 
 // loop's sums term for term.  igranu 1: log-normal (v1 modal radius, v2 ln-std); 2: Junge (v1 = r0, v2 slope, v3 = rmax).
 //   out[0..2] = KMAT1 / SOMME_NR, KMAT2 / SOMME_NR, SOMME_NR;  out[3 + c W + j] = P11 | P12 | P33 (normalised by KMAT2)
 // work[3 na + 1]: x1 qext | qsca x1 | nr pr, and the number of records used (the loop's exit, :4520 / :4585).
-__global__ void k_granu(int na, int nbmu, const float *__restrict__ rec, int igranu, double v1, double v2, double v3, double wa,
-                        double alphaf, double *__restrict__ work, double *__restrict__ out)
+__device__ __forceinline__ void granu_block(int na, int nbmu, const float *__restrict__ rec, int igranu, double v1, double v2, double v3,
+                                            double wa, double alphaf, double *__restrict__ work, double *__restrict__ out)
 {
     __shared__ int s_nuse;
     const int t = threadIdx.x, W = 2 * nbmu + 1, RS = 4 + 3 * W;
@@ -287,8 +287,34 @@ __global__ void k_granu(int na, int nbmu, const float *__restrict__ rec, int igr
     if (t == 0) work[3 * (size_t)na] = (double)nuse;
 }
 
+// Several size integrals in one launch, one workgroup each (the wavelengths of a spectrum: run_sos.sos_spectrum asks for the
+// integrals of a batch of wavelengths ahead of their host preparation).  The jobs travel as the kernel argument (32 x 64 bytes).
+struct GranuJobs { sosgpu_granu_job j[SOSGPU_GRANU_JOBS_PER_LAUNCH]; };
+
+__global__ __launch_bounds__(256) void k_granu_batch(const GranuJobs jobs, int nbmu, double *__restrict__ work, size_t work_stride,
+                                                     double *__restrict__ out)
+{
+    const sosgpu_granu_job &jb = jobs.j[blockIdx.x];
+    granu_block(jb.nalpha, nbmu, jb.d_rec, jb.igranu, jb.v1, jb.v2, jb.v3, jb.wa, jb.alphaf, work + blockIdx.x * work_stride,
+                out + (size_t)blockIdx.x * (3 + 3 * (2 * nbmu + 1)));
+}
+
 void launch_granu(int na, int nbmu, const float *d_rec, int igranu, double v1, double v2, double v3, double wa, double alphaf,
                   double *d_work, double *d_out, hipStream_t st)
 {
-    k_granu<<<1, 256, 0, st>>>(na, nbmu, d_rec, igranu, v1, v2, v3, wa, alphaf, d_work, d_out);
+    void launch_granu_batch(int, int, const sosgpu_granu_job *, double *, size_t, double *, hipStream_t);
+    sosgpu_granu_job jb = {d_rec, na, igranu, v1, v2, v3, wa, alphaf};       // (one kernel for both entry points: the same sums)
+    launch_granu_batch(1, nbmu, &jb, d_work, (size_t)3 * na + 1, d_out, st);
+}
+
+void launch_granu_batch(int count, int nbmu, const sosgpu_granu_job *jobs, double *d_work, size_t work_stride, double *d_out,
+                        hipStream_t st)
+{
+    const size_t nout = (size_t)3 + 3 * (2 * nbmu + 1);
+    for (int c0 = 0; c0 < count; c0 += SOSGPU_GRANU_JOBS_PER_LAUNCH) {
+        const int n = count - c0 < SOSGPU_GRANU_JOBS_PER_LAUNCH ? count - c0 : SOSGPU_GRANU_JOBS_PER_LAUNCH;
+        GranuJobs jb = {};
+        for (int k = 0; k < n; k++) jb.j[k] = jobs[c0 + k];
+        k_granu_batch<<<n, 256, 0, st>>>(jb, nbmu, d_work + (size_t)c0 * work_stride, work_stride, d_out + (size_t)c0 * nout);
+    }
 }

@@ -736,12 +736,15 @@ def _trphi_azimuths(itrphi, phios, pas_phi):
     return phis, rows, phi_fin
 
 
-def _trphi_pack(n, mu, out, rows, phi_fin):
-    """sosgpu_trphi's [nphi][7][W] (host array) -> PHI_FIN, THETA_FIN and the fourteen (361,81) tables."""
+def _trphi_pack(n, mu, out, rows, phi_fin, block=None):
+    """sosgpu_trphi's [nphi][7][W] (host array) -> PHI_FIN, THETA_FIN and the fourteen (361,81) tables.
+    block: zeroed (2,7,361,81) array to fill (sos_spectrum hands out slices of one allocation per chunk of wavelengths: 3.3 MB
+    blocks allocated one by one come from the heap and are cleared by hand, 0.3 ms each; one large block is fresh zero pages)."""
     theta_fin = np.zeros(81)
     theta_fin[:n] = np.degrees(np.arccos(mu))
     names = ["i", "q", "u", "sca", "ang", "rate", "lpol"]       # order of sosgpu_trphi's 7 output rows
-    block = np.zeros((2, 7, 361, 81))                           # the fourteen tables in one allocation
+    if block is None:
+        block = np.zeros((2, 7, 361, 81))                       # the fourteen tables in one allocation
     nr = len(rows)
     block[0][:, rows, :n] = out[:nr, :, n + 1:].transpose(1, 0, 2)            # up-going jj = 1..N
     block[1][:, rows, :n] = out[:nr, :, :n][:, :, ::-1].transpose(1, 0, 2)    # down-going jj = -1..-N
@@ -782,6 +785,25 @@ def _aerosols_at_waref(p, nb_mie, os_nb, device):
         while len(_AER_REF_CACHE) > 16:
             _AER_REF_CACHE.popitem(last=False)
     return out
+
+
+def _size_integral_requests(kw, aer_phase, device):
+    """The size integrals the aerosol step of _prepare(kw, aer_phase) will ask for at the simulation wavelength (keys of
+    aerosols.prefetch_size_integrals); empty when the step does not run or its parameters are refused (the real pass reports)."""
+    from . import aerosols as _aer
+    try:
+        p = dict(kw)
+        validate_parameters(p)
+        if (p["aot_ref"] in (0.0, _D) or aer_phase is not None or str(p["ficuser_aer"]).strip() != "NO_USER_AEROSOLS"
+                or p["waref_aot"] == _D or p["wa_simu"] in (_D, p["waref_aot"])):
+            return []
+        nb_mie = CTE_DEFAULT_NBMU_MIE if p["nbmu_gauss_mie"] == _I else int(p["nbmu_gauss_mie"])
+        os_nb = CTE_DEFAULT_OS_NB if p["nbmu_gauss_mie"] == _I else 2 * nb_mie
+        with _aer.collect_size_integrals() as reqs:
+            _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device)
+        return reqs
+    except Exception:
+        return []
 
 
 def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
@@ -1048,14 +1070,14 @@ def _trphi_launch(pl, rec0, nf, tau, tauout):
     return pl.ctx.trphi(rec0, nf, tau, tauout, phis, igli=pl.igli, wind=pl.p["wind"] if pl.igli else 0.0, land=pl.land)
 
 
-def _finish(pl, out, rec0, fin, g=0):
+def _finish(pl, out, rec0, fin, g=0, block=None):
     """The tail of SOS_PROC (SOS_PROC.F:3755-3874) on the host: the (361,81) tables from sosgpu_trphi's output `out` (host
     array), fluxes, result files (rank 0 only), the 23-tuple.  rec0: aggregated records [S][3][W] of this wavelength
     (device); fin: dist.finish_scalars dictionary, g the wavelength's segment in it."""
     p, n, mu = pl.p, pl.n, pl.mu
     nf = int(fin["n_orders"][g])
     tau_agg, ttot_vrai_agg = float(fin["ttot_tronc"][g]), float(fin["ttot_vrai"][g])
-    phi_fin, theta_fin, up, dn = _trphi_pack(n, mu, out, pl.rows, pl.phi_fin)
+    phi_fin, theta_fin, up, dn = _trphi_pack(n, mu, out, pl.rows, pl.phi_fin, block)
     emoins, eplus = float(fin["emoins"][g]), float(fin["eplus"][g])
     from . import absorption as _abs
     resbin = str(p["ficsos_res_bin"]).strip()
@@ -1250,6 +1272,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     from . import capi
     from .solver import ContextTable, SosBinError, concat_bins, solve_spectrum
     from . import dist as _dist
+    from . import aerosols as _aer
     capi.lib()
     nwl = len(kwargs_list)
     if aer_phases is None:
@@ -1279,6 +1302,13 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
             # device, and the launches below wait for all of them
             for st in side + [aer_st]:
                 st.wait_stream(main_st)
+            # the size-distribution integrals of the chunk's wavelengths, queued ahead (aerosols.prefetch_size_integrals)
+            reqs = []
+            for i in idx:
+                reqs += _size_integral_requests(kwargs_list[i], aer_phases[i], device)
+            if reqs:
+                with torch.cuda.stream(aer_st):
+                    _aer.prefetch_size_integrals(reqs)
             for k, i in enumerate(idx):
                 with torch.cuda.stream(side[k % len(side)]):
                     pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
@@ -1343,16 +1373,18 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
             t4 = time.perf_counter()
             tm["trphi"] += t4 - t3
             pos, k = 0, 0
+            blocks = np.zeros((len(outs), 2, 7, 361, 81))     # the result tables of the chunk's wavelengths (views of it)
             for gp, _, _, _ in solved:
                 for pl in gp:
                     cnt = outs[k].numel()
-                    results[pl.index] = _finish(pl, flat[pos:pos + cnt].reshape(outs[k].shape), pl.rec0, pl.fin, pl.g)
+                    results[pl.index] = _finish(pl, flat[pos:pos + cnt].reshape(outs[k].shape), pl.rec0, pl.fin, pl.g, blocks[k])
                     nrows[pl.index] = len(pl.rows)
                     pos += cnt
                     k += 1
             tm["finish"] += time.perf_counter() - t4
         finally:
-            for st in side:
+            _aer.drop_prefetched_size_integrals()
+            for st in side + [aer_st]:
                 st.synchronize()
             main_st.synchronize()                             # the table launches read every context's operators
             for pl in plans:

@@ -5,7 +5,9 @@ arithmetic happens in libsosgpu.so (capi.py), and there is no CPU fallback.
 Mirrors the reference per-wavelength sequence of SOS_PROC (src/SOS_PROC.F:3423-3594):
   SOS_PREPA_OS -> [per bin: SOS (truncation rescale) -> SOS_OS -> SOS_AGGREGATE].
 """
+import collections
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -26,13 +28,46 @@ def _dev_f64(x, device):
     a = np.ascontiguousarray(x, dtype=np.float64)
     if not a.flags.writeable:                      # (cached read-only tables: torch wants a writable buffer to wrap)
         a = a.copy()
-    return torch.from_numpy(a).to(device)
+    return _upload(torch.from_numpy(a), device)
+
+
+def _upload(t, device):
+    """Host tensor -> device on the current stream without a host wait: through a pinned staging block of torch's host
+    allocator (returned to it when the copy has passed).  A pageable `.to(device)` waits for the stream -- behind whatever
+    preparation kernels sos_spectrum has queued there."""
+    if t.numel() == 0 or t.numel() * t.element_size() > (4 << 20) or torch.device(device).type != "cuda":
+        return t.to(device)                        # (large tables: uploaded once per batch, not worth a pinned block)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def _dev_i32(x, device):
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.int32).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(device)
+    return _upload(torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)), device)
+
+
+_CONST_DEV = collections.OrderedDict()
+_CONST_LOCK = threading.Lock()
+
+
+def _const_dev_f64(x, device):
+    """Device copy of a SMALL host array that repeats from call to call (altitude grid of the gas profiles, azimuth list of a
+    view): kept per (content, device) -- a pageable upload is a host-synchronous 30 us, a spectrum makes thousands of them."""
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if a.nbytes > 8192:
+        return _dev_f64(a, device)
+    key = (a.tobytes(), str(device))
+    with _CONST_LOCK:
+        hit = _CONST_DEV.get(key)
+        if hit is not None:
+            _CONST_DEV.move_to_end(key)
+            return hit
+    t = torch.from_numpy(a.copy()).to(device)              # (synchronous copy: complete, usable from any stream)
+    with _CONST_LOCK:
+        _CONST_DEV[key] = t
+        while len(_CONST_DEV) > 64:
+            _CONST_DEV.popitem(last=False)
+    return t
 
 
 def _ptr(t):
@@ -152,8 +187,19 @@ class SosContext:
         exponential term per gas, xk[8][nterm][nlev-1] / ro[8][nlev-1] from absorption.layer_tables.  Returns the device
         tensor tabs[nb][nlev] that make_profiles takes."""
         d = self.device
-        ik_t = _dev_i32(np.ascontiguousarray(ik, dtype=np.int32), d)
-        xk_t, ro_t = _dev_f64(xk, d), _dev_f64(ro, d)
+        if isinstance(ik, torch.Tensor) or isinstance(xk, torch.Tensor) or isinstance(ro, torch.Tensor):
+            ik_t = _dev_i32(ik, d)
+            xk_t, ro_t = _dev_f64(xk, d), _dev_f64(ro, d)
+        else:
+            # one upload for the three tables (8-byte units; a bin's eight int32 indices are four of them)
+            ik_h = np.ascontiguousarray(ik, dtype=np.int32)
+            xk_h, ro_h = np.ascontiguousarray(xk, dtype=np.float64), np.ascontiguousarray(ro, dtype=np.float64)
+            if ik_h.ndim != 2 or ik_h.shape[1] != 8:
+                raise ValueError("ik must be [nb][8], xk [8][nterm][nlev-1], ro [8][nlev-1]")
+            buf = _upload(torch.from_numpy(np.concatenate([xk_h.ravel(), ro_h.ravel(), ik_h.ravel().view(np.float64)])), d)
+            xk_t = buf[:xk_h.size].view(xk_h.shape)
+            ro_t = buf[xk_h.size:xk_h.size + ro_h.size].view(ro_h.shape)
+            ik_t = buf[xk_h.size + ro_h.size:].view(torch.int32).view(ik_h.shape)
         nb, nterm, nlev = int(ik_t.shape[0]), int(xk_t.shape[1]), int(xk_t.shape[2]) + 1
         if tuple(ik_t.shape) != (nb, 8) or xk_t.shape[0] != 8 or tuple(ro_t.shape) != (8, nlev - 1):
             raise ValueError("ik must be [nb][8], xk [8][nterm][nlev-1], ro [8][nlev-1]")
@@ -175,7 +221,7 @@ class SosContext:
         if tabs is not None:
             t_tab = tabs if isinstance(tabs, torch.Tensor) else np.atleast_2d(np.asarray(tabs, dtype=np.float64))
             t_tab = _dev_f64(t_tab, d)
-            t_alt = _dev_f64(np.asarray(altabs, dtype=np.float64), d)
+            t_alt = _const_dev_f64(altabs, d)
             nblev = int(t_alt.numel())
             if t_tab.shape != (nb, nblev):
                 raise ValueError("tabs must be [nb][len(altabs)]")
@@ -315,7 +361,7 @@ class SosContext:
         (aggregated records).  Returns a device tensor [nphi][7][W]: XIT, XQT, XUT, ANGDIFF, polarisation
         angle, polarisation rate, polarised radiance."""
         d = self.device
-        phis = _dev_f64(np.atleast_1d(np.asarray(phis_rad, dtype=np.float64)), d)
+        phis = _const_dev_f64(np.atleast_1d(np.asarray(phis_rad, dtype=np.float64)), d)
         rec = rec.to(device=d, dtype=torch.float64).contiguous()
         out = torch.empty((phis.numel(), 7, self.w), dtype=torch.float64, device=d)
         lp = None if land is None else C.byref(land)          # capi.Land: direct term of the land model (-SURF.Type 3..7)

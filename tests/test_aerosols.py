@@ -133,6 +133,54 @@ def test_device_size_integral_vs_host_restatement(gpu_pkg):
 
 
 @pytest.mark.gpu
+def test_size_integrals_queued_ahead_equal_the_direct_calls(gpu_pkg):
+    """sosgpu_granu_batch (what sos_spectrum queues for a batch of wavelengths) against sosgpu_granu, bit for bit: 70 jobs over
+    three launches, two record sets of different length, both laws; then the collect -> prefetch -> model pass of a bimodal
+    aerosol model against the plain pass."""
+    import torch
+    A, rs = gpu_pkg.aerosols, gpu_pkg.run_sos
+    xmu, _ = A.mie_angles(12)
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(70):
+        if k % 3 == 2:
+            jobs.append((1.33, -0.001, 100.0, 2, 0.03 + 0.01 * rng.random(), 3.5 + rng.random(), 8.0 + 4 * rng.random(),
+                         0.4 + 1.5 * rng.random()))
+        else:
+            jobs.append((1.45, -0.003, 300.0 if k % 2 else 100.0, 1, 0.05 + 0.5 * rng.random(), 0.3 + 0.4 * rng.random(), -999.0,
+                         0.4 + 1.5 * rng.random()))
+    direct = [A.size_integral(xmu, rn, in_, af, ig, v1, v2, v3, wa) for rn, in_, af, ig, v1, v2, v3, wa in jobs]
+    keys = [A._granu_key(xmu, rn, in_, af, ig, v1, v2, v3, wa, 0) for rn, in_, af, ig, v1, v2, v3, wa in jobs]
+    try:
+        assert A.prefetch_size_integrals(keys + keys[:5]) == 70
+        ahead = [A.size_integral(xmu, rn, in_, af, ig, v1, v2, v3, wa) for rn, in_, af, ig, v1, v2, v3, wa in jobs]
+    finally:
+        A.drop_prefetched_size_integrals()
+    for d, a in zip(direct, ahead):
+        assert d[:3] == a[:3]
+        for x, y in zip(d[3:], a[3:]):
+            assert np.array_equal(x, y)
+    # the model code in collect mode names exactly the integrals its real pass asks for
+    g = np.load(os.path.join(GOLD, "sos_proc_cfg4_glitter_bilnd.npz"))
+    user = json.loads(str(g["user_json"]))
+    p = rs.sos_proc_kwargs(rs.update_parameters(rs.default_parameters(), user), trace=False)
+    nb_mie = int(user["-ANG.Aer.NbGauss"])
+    plain = A.aerosols(p, 0.7, 0.1, nb_mie, 2 * nb_mie, at_waref=False)
+    with A.collect_size_integrals() as reqs:
+        assert A.aerosols(p, 0.7, 0.1, nb_mie, 2 * nb_mie, at_waref=False) is None
+    assert len(reqs) >= 2
+    try:
+        A.prefetch_size_integrals(reqs)
+        ahead = A.aerosols(p, 0.7, 0.1, nb_mie, 2 * nb_mie, at_waref=False)
+    finally:
+        A.drop_prefetched_size_integrals()
+    for k in ("alpha", "beta", "gamma", "zeta"):
+        assert np.array_equal(plain[k], ahead[k]), k
+    assert plain["kmat1"] == ahead["kmat1"] and plain["coef_tronca"] == ahead["coef_tronca"]
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
 def test_aerosol_model_vs_reference_aerosols_file(gpu_pkg, name):
     rs, A = gpu_pkg.run_sos, gpu_pkg.aerosols
