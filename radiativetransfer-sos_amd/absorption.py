@@ -446,11 +446,10 @@ def coeff_abs_ckd_rows(nabs, ki, tab_pres, tab_temp, tab_conc, prs, tmp, conc):
     return xk, prs, tmp, conc
 
 
-def layer_tables(prep):
-    """XK(gas, term, layer) RO(gas, layer) of SOS_ABSPROFILE.F:325-353 for every exponential term of every gas:
-    returns (xk [8][5][49], ro [8][49]) with layer index J-1, J = 1 the TOP layer (the reference's loop order).
-    All 49 layers of a (term, gas) pair are interpolated together (coeff_abs_ckd_rows); the clamped pressure / temperature /
-    water-vapour state is carried from gas to gas per layer exactly as the reference carries it."""
+def layer_tables_by_pair(prep):
+    """layer_tables, one coeff_abs_ckd_rows call per (term, gas) pair with the clamped pressure / temperature / water-vapour
+    state carried from gas to gas per layer as the reference carries it (the form of round 2; now the checker of layer_tables in
+    tests/test_absorption.py, between it and the layer-by-layer layer_tables_scalar)."""
     u = prep["userprofil"]
     nl = NLEVEL
     xk = np.zeros((NBABS, CKD_NAI_MAX, nl - 1))
@@ -467,6 +466,152 @@ def layer_tables(prep):
             xk[k, term], prs, tmp, conc = coeff_abs_ckd_rows(k + 1, prep["ki"][k][term], prep["tab_pres"], prep["tab_temp"],
                                                              prep["tab_conc"], prs, tmp, conc)
     ro = prep["ro"][:, nl - j - 1].copy()             # RO(K, NLEVEL-J)
+    return xk, ro
+
+
+class _LayerGeometry:
+    """Everything of COEFF_ABS_CKD that depends on the atmosphere and the table axes only, for the 49 layers."""
+
+
+@functools.lru_cache(maxsize=8)
+def _layer_geometry(u_bytes, pres_bytes, temp_bytes, conc_bytes):
+    """Brackets and weights of the three interpolations of COEFF_ABS_CKD (src/SOS_SUB_TRS.F:171) for the 49 layers of an
+    atmosphere on given table axes.  The state the reference carries from gas to gas (pressure, temperature and water-vapour
+    concentration clamped to the tables) is the same clamp for every gas -- idempotent -- and every interpolation works on the
+    clamped values: the geometry is one per atmosphere, whatever gases and terms are present."""
+    u = np.frombuffer(u_bytes, dtype=np.float64).reshape(NLEVEL, -1)
+    tab_pres, x, tab_conc = (np.frombuffer(b, dtype=np.float64) for b in (pres_bytes, temp_bytes, conc_bytes))
+    nl = NLEVEL
+    j = np.arange(1, nl)
+    lo, hi = nl - j - 1, nl - j
+    prs = (u[lo, 1] + u[hi, 1]) / 2.
+    tmp = (u[lo, 2] + u[hi, 2]) / 2.
+    conc = (u[lo, 3] + u[hi, 3]) / 2.
+    conc = conc * 1.e-06
+    g = _LayerGeometry()
+    tmp = np.minimum(np.maximum(tmp, x[0]), x[-1])
+    g.act = ~(prs <= tab_pres[0])
+    g.n = int(g.act.sum())
+    if not g.n:
+        return g
+    g.pa = pa = np.minimum(prs[g.act], tab_pres[-1])
+    g.ta = ta = tmp[g.act]
+    g.ca = ca = np.minimum(np.maximum(conc[g.act], tab_conc[0]), tab_conc[-1])
+    g.ip = ip = _bracket(tab_pres, pa)
+    g.ic = ic = _bracket(tab_conc, ca)
+    g.c0, g.c1 = tab_conc[ic][:, None, None], tab_conc[ic + 1][:, None, None]
+    g.cd = ca[:, None, None] - g.c1
+    g.p1 = tab_pres[ip + 1][:, None]
+    g.pw = g.p1 - tab_pres[ip][:, None]
+    g.pd = pa[:, None] - g.p1
+    nt = len(x)
+    klo = np.zeros(g.n, dtype=np.int64); khi = np.full(g.n, nt - 1, dtype=np.int64)
+    while np.any(khi - klo > 1):                       # _splint's bisection, as in coeff_abs_ckd_rows
+        k = (khi + klo + 2) // 2 - 1
+        go = khi - klo > 1
+        up = x[k] > ta
+        khi = np.where(go & up, k, khi)
+        klo = np.where(go & ~up, k, klo)
+    g.klo, g.khi, g.rows = klo, khi, np.arange(g.n)
+    g.h = h = x[khi] - x[klo]
+    g.bad_h = bool(np.any(h == 0.))
+    if not g.bad_h:
+        g.aa = aa = (x[khi] - ta) / h
+        g.bb = bb = (ta - x[klo]) / h
+        g.a3, g.b3, g.h2 = aa * aa * aa - aa, bb * bb * bb - bb, h * h
+    g.it = it = _bracket(x, ta)
+    g.lw = x[it + 1] - x[it]
+    g.ld = ta - x[it + 1]
+    # the forward sweep of the spline's tridiagonal solve for a finite first slope: SIG, P and the factor D2(K) depend on the
+    # temperatures alone (the scalars the row form computes per row)
+    sig, pk, dk = np.zeros(nt), np.zeros(nt), np.zeros(nt)
+    dk[0] = -0.5
+    for k in range(1, nt - 1):
+        sig[k] = (x[k] - x[k - 1]) / (x[k + 1] - x[k - 1])
+        pk[k] = sig[k] * dk[k - 1] + 2.
+        dk[k] = (sig[k] - 1.) / pk[k]
+    g.sig, g.pk, g.dk = sig, pk, dk
+    g.dx = x[1:] - x[:-1]                              # X(K+1) - X(K)
+    g.dx2 = x[2:] - x[:-2]                             # X(K+1) - X(K-1)
+    return g
+
+
+def _spline_rows_finite(g, x, y, dy1, dyn):
+    """_spline_rows for finite end slopes, with the x-only quantities of the forward sweep taken from the geometry: the same
+    statements on the same values, element by element."""
+    n = len(x)
+    d2 = np.empty_like(y)
+    u = np.empty_like(y)
+    u[:, 0] = (3. / (x[1] - x[0])) * ((y[:, 1] - y[:, 0]) / (x[1] - x[0]) - dy1)
+    sl = (y[:, 1:] - y[:, :-1]) / g.dx                                  # (Y(K+1) - Y(K)) / (X(K+1) - X(K)), K = 0 .. n-2
+    t = 6. * (sl[:, 1:] - sl[:, :-1]) / g.dx2                           # column K-1 holds the term of row K = 1 .. n-2
+    for k in range(1, n - 1):
+        u[:, k] = (t[:, k - 1] - g.sig[k] * u[:, k - 1]) / g.pk[k]
+    un = (3. / (x[n - 1] - x[n - 2])) * (dyn - (y[:, n - 1] - y[:, n - 2]) / (x[n - 1] - x[n - 2]))
+    d2[:, n - 1] = (un - 0.5 * u[:, n - 2]) / (0.5 * g.dk[n - 2] + 1.)
+    for k in range(n - 2, -1, -1):
+        d2[:, k] = g.dk[k] * d2[:, k + 1] + u[:, k]
+    return d2
+
+
+def layer_tables(prep):
+    """XK(gas, term, layer) RO(gas, layer) of SOS_ABSPROFILE.F:325-353 for every exponential term of every gas:
+    returns (xk [8][5][49], ro [8][49]) with layer index J-1, J = 1 the TOP layer (the reference's loop order).
+    The 49 layers of ALL (term, gas) pairs with a non-zero table are interpolated together, on brackets and weights kept per
+    atmosphere (_layer_geometry: a spectrum shares one atmosphere); element by element the arithmetic of coeff_abs_ckd --
+    tests/test_absorption.py holds it against the pair-by-pair and the layer-by-layer forms, bit for bit."""
+    u = prep["userprofil"]
+    nl = NLEVEL
+    xk = np.zeros((NBABS, CKD_NAI_MAX, nl - 1))
+    j = np.arange(1, nl)
+    ro = prep["ro"][:, nl - j - 1].copy()             # RO(K, NLEVEL-J)
+    x = prep["tab_temp"]
+    g = _layer_geometry(np.ascontiguousarray(u).tobytes(), np.ascontiguousarray(prep["tab_pres"]).tobytes(),
+                        np.ascontiguousarray(x).tobytes(), np.ascontiguousarray(prep["tab_conc"]).tobytes())
+    if g.n:
+        pairs, a0s, a1s = [], [], []
+        for term in range(CKD_NAI_MAX):
+            for k in range(NBABS):
+                if term >= prep["nexp"][k]:
+                    continue
+                ki = prep["ki"][k][term]
+                if not ki.any():                       # NMAXAI = 0: the gas does not absorb here, every interpolation of zeros is zero
+                    continue
+                if k == 0:                             # water vapour: first along the concentration axis
+                    k0, k1 = ki[g.ic], ki[g.ic + 1]                            # [La][NP][NT]
+                    xkh = ((k1 - k0) / (g.c1 - g.c0)) * g.cd + k1
+                    a0, a1 = xkh[g.rows, g.ip], xkh[g.rows, g.ip + 1]
+                else:
+                    a0, a1 = ki[g.ip], ki[g.ip + 1]                            # [La][NT]
+                pairs.append((k, term))
+                a0s.append(a0)
+                a1s.append(a1)
+        if pairs:
+            if g.bad_h:
+                raise AbsorptionError("ERROR for SPLINT interpolation")
+            npair, la = len(pairs), g.n
+            a0, a1 = np.stack(a0s), np.stack(a1s)                              # [pairs][La][NT]
+            xki = (((a1 - a0) / g.pw) * g.pd + a1).reshape(npair * la, -1)
+            dy1 = (xki[:, 1] - xki[:, 0]) / (x[1] - x[0])
+            dyn = (xki[:, -1] - xki[:, -2]) / (x[-1] - x[-2])
+            if np.any(dy1 > _F(.99E30)) or np.any(dyn > _F(.99E30)):
+                d2 = _spline_rows(x, xki, dy1, dyn)
+            else:
+                d2 = _spline_rows_finite(g, x, xki, dy1, dyn)
+            rows = np.arange(npair * la)
+            klo, khi = np.tile(g.klo, npair), np.tile(g.khi, npair)
+            tl = lambda a: np.tile(a, npair)
+            val = tl(g.aa) * xki[rows, klo] + tl(g.bb) * xki[rows, khi] + (tl(g.a3) * d2[rows, klo] + tl(g.b3) * d2[rows, khi]) * tl(g.h2) / 6.
+            neg = val < 0.
+            if neg.any():
+                it = tl(g.it)
+                lin = ((xki[rows, it + 1] - xki[rows, it]) / tl(g.lw)) * tl(g.ld) + xki[rows, it + 1]
+                val = np.where(neg, lin, val)
+                if np.any(val < 0.):
+                    raise AbsorptionError("COEFF_ABS_CKD : ERROR_923 : Calculations give ki < 0 : uncorrect value!")
+            val = val.reshape(npair, la)
+            for q, (k, term) in enumerate(pairs):
+                xk[k, term][g.act] = val[q]
     return xk, ro
 
 

@@ -278,52 +278,57 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
             else { fres[j - 1] = f11; fres[N + j - 1] = f12; fres[2 * N + j - 1] = f33; }
         }
     }
-    double *p;
     int rc;
     hipStream_t us = util_stream(device);
     if (!us) { delete cx; return SOSGPU_E_HIP; }
-#define UP(dst, src, cnt)                                                                     \
-    if ((rc = dev_alloc(cx, &p, (cnt)))) { sosgpu_destroy(cx); return rc; }                   \
-    if (hipMemcpyAsync(p, (src), (cnt) * sizeof(double), hipMemcpyHostToDevice, us) != hipSuccess) {   \
-        sosgpu_destroy(cx); return SOSGPU_E_HIP; }                                            \
-    dst = p;
-    UP(d.mu, mu, (size_t)N)
-    UP(d.ga, ga, (size_t)N)
-    UP(d.coef, coef.data(), coef.size())
-    UP(d.fres, fres.data(), fres.size())
-#undef UP
-    {
-        int32_t *q = nullptr;
-        if ((rc = dev_alloc(cx, &q, rowmap.size()))) { sosgpu_destroy(cx); return rc; }
-        if (hipMemcpyAsync(q, rowmap.data(), rowmap.size() * sizeof(int32_t), hipMemcpyHostToDevice, us) != hipSuccess) {
-            sosgpu_destroy(cx); return SOSGPU_E_HIP; }
-        d.rowmap = q;
-        d.nwgt = nwgt;
+    // The context's small tables share ONE allocation, filled by ONE copy from a pinned block of the calling thread and one
+    // memset: [mu | ga | coef | fres | rowmap] copied, [mp_vt | mp_uf] cleared (a spectrum creates one context per
+    // wavelength: five pageable uploads, two fills and ten pool requests were 0.2 ms of each).  Offsets in doubles, each
+    // a multiple of 32 (256-byte alignment of the operator fragments).
+    auto up32 = [](size_t v) { return (v + 31) & ~(size_t)31; };
+    const size_t o_mu = 0, o_ga = up32(o_mu + N), o_coef = up32(o_ga + N), o_fres = up32(o_coef + coef.size()),
+                 o_map = up32(o_fres + fres.size()), o_vt = up32(o_map + (rowmap.size() + 1) / 2),
+                 n_vt = (size_t)3 * d.ks2h * 128, n_uf = (size_t)3 * d.rtph * 64, o_uf = up32(o_vt + n_vt), n_small = o_uf + n_uf;
+    double *small = nullptr;
+    if ((rc = dev_alloc(cx, &small, n_small))) { sosgpu_destroy(cx); return rc; }
+    static thread_local double *stage = nullptr;           // (kept for the life of the thread: 64 KB at the largest N and OS_NB)
+    static thread_local size_t stage_n = 0;
+    if (stage_n < o_vt) {
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr; stage_n = 0;
+        if (hipHostMalloc((void **)&stage, up32(o_vt + 4096) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError(); sosgpu_destroy(cx); return SOSGPU_E_HIP; }
+        stage_n = up32(o_vt + 4096);
     }
+    memset(stage, 0, o_vt * sizeof(double));
+    memcpy(stage + o_mu, mu, (size_t)N * sizeof(double));
+    memcpy(stage + o_ga, ga, (size_t)N * sizeof(double));
+    memcpy(stage + o_coef, coef.data(), coef.size() * sizeof(double));
+    memcpy(stage + o_fres, fres.data(), fres.size() * sizeof(double));
+    memcpy(stage + o_map, rowmap.data(), rowmap.size() * sizeof(int32_t));
+    d.mu = small + o_mu; d.ga = small + o_ga; d.coef = small + o_coef; d.fres = small + o_fres;
+    d.rowmap = reinterpret_cast<int32_t *>(small + o_map);
+    d.nwgt = nwgt;
+    d.mp_vt = small + o_vt; d.mp_uf = small + o_uf;
     const size_t per = (size_t)2 * d.rtph * d.ks2h * 128;
     if ((rc = dev_alloc(cx, &d.prt, (size_t)(d.smax + 1) * 3 * (B + 1) * d.w)) ||
         (rc = dev_alloc(cx, &d.mp_aer, (size_t)(d.smax + 1) * per)) ||
-        (rc = dev_alloc(cx, &d.mp_vt, (size_t)3 * d.ks2h * 128)) ||
-        (rc = dev_alloc(cx, &d.mp_uf, (size_t)3 * d.rtph * 64)) ||
         (rc = dev_alloc(cx, &d.sv, (size_t)(d.smax + 1) * 4 * d.kp))) {
         sosgpu_destroy(cx);
         return rc;
     }
-    // The uploads above (their host sources are locals of this call) and the two fills run on the calling thread's utility
-    // stream and are waited for here: when the call returns every table is in place, whatever stream sosgpu_noyaux and the
-    // solves are queued on afterwards.  (Round 2 filled on the null stream: a non-blocking caller stream does not wait for it,
-    // and a fill could land on top of the molecular operator sosgpu_noyaux had already packed.)
-    if (hipMemsetAsync(d.mp_vt, 0, (size_t)3 * d.ks2h * 128 * sizeof(double), us) != hipSuccess ||
-        hipMemsetAsync(d.mp_uf, 0, (size_t)3 * d.rtph * 64 * sizeof(double), us) != hipSuccess ||
+    // The upload and the fill run on the calling thread's utility stream and are waited for here (the pinned block is reused by
+    // the thread's next call): when the call returns every table is in place, whatever stream sosgpu_noyaux and the solves are
+    // queued on afterwards.  (Round 2 filled on the null stream: a non-blocking caller stream does not wait for it, and a fill
+    // could land on top of the molecular operator sosgpu_noyaux had already packed.)
+    if (hipMemcpyAsync(small, stage, o_vt * sizeof(double), hipMemcpyHostToDevice, us) != hipSuccess ||
+        hipMemsetAsync(small + o_vt, 0, (n_small - o_vt) * sizeof(double), us) != hipSuccess ||
         hipStreamSynchronize(us) != hipSuccess) {
         g_last_hip = (int)hipGetLastError();
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;
     }
-    if (hipEventCreate(&cx->ev0) != hipSuccess || hipEventCreate(&cx->ev1) != hipSuccess) {
-        sosgpu_destroy(cx);
-        return SOSGPU_E_HIP;
-    }
+    cx->ev0 = cx->ev1 = nullptr;                           // (created by the first solve)
     *out = cx;
     return SOSGPU_OK;
 }
@@ -596,6 +601,8 @@ static int os_solve_impl(sosgpu_ctx *cx, const SosDev *table, const int32_t *d_c
     // (The scratch is reused from solve to solve and from context to context -- pool above -- without being cleared: the streamed
     //  kernel initialises what it reads; the pad levels and pad columns it stages along with a chunk feed columns / rows of
     //  the contraction that are never stored.)
+    if (!cx->ev0) { HIPCHK(hipEventCreate(&cx->ev0)); }
+    if (!cx->ev1) { HIPCHK(hipEventCreate(&cx->ev1)); }
     HIPCHK(hipEventRecord(cx->ev0, st));
     const int S1 = cx->d.smax + 1, W = cx->d.w;
     for (int b0 = 0; b0 < nb; b0 += per_launch) {

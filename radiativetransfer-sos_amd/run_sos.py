@@ -282,11 +282,34 @@ def write_mie_angles(path, nb_gauss, os_nb, user_file="NO_USER_ANGLES"):
 # ---------------------------------------------------------------------------------------------------------
 # host-side restatements of the steps before the hot path (inputs of SOS_OS)
 # ---------------------------------------------------------------------------------------------------------
+_ANGLES_CACHE = collections.OrderedDict()
+
+
 def angles(nbmu_gauss, tetas, user_file="NO_USER_ANGLES"):
     """SOS_ANGLES for the radiance angles (SOS_ANGLES.F:380-466, 713-866): Gauss nodes/weights of the
     2*NbGauss-point rule on [-1,1] (positive half), optional user angles (weight 0), solar angle inserted
     with weight 0 unless it coincides with a node, mu descending; values as re-read from SOS_UsedAngles.txt
-    (D21.14).  Returns mu[N], ga[N], n0 (1-based), ind_angout[N] (1 = user angle)."""
+    (D21.14).  Returns mu[N], ga[N], n0 (1-based), ind_angout[N] (1 = user angle).
+    The last few angle sets are kept (the calls of a spectrum share theirs; a user file is keyed by its size and time stamp)."""
+    key = (int(nbmu_gauss), float(tetas), str(user_file))
+    if user_file != "NO_USER_ANGLES":
+        try:
+            st = os.stat(user_file)
+            key += (st.st_size, st.st_mtime_ns)
+        except OSError:
+            key = None
+    hit = _ANGLES_CACHE.get(key) if key is not None else None
+    if hit is None:
+        hit = _angles(nbmu_gauss, tetas, user_file)
+        if key is not None:
+            _ANGLES_CACHE[key] = hit
+            while len(_ANGLES_CACHE) > 16:
+                _ANGLES_CACHE.popitem(last=False)
+    mu, ga, n0, ind = hit
+    return mu.copy(), ga.copy(), n0, ind.copy()
+
+
+def _angles(nbmu_gauss, tetas, user_file):
     x, w = sos_gauss(nbmu_gauss)
     mu = list(x)
     wt = list(w)
@@ -746,8 +769,10 @@ def _trphi_pack(n, mu, out, rows, phi_fin, block=None):
     if block is None:
         block = np.zeros((2, 7, 361, 81))                       # the fourteen tables in one allocation
     nr = len(rows)
-    block[0][:, rows, :n] = out[:nr, :, n + 1:].transpose(1, 0, 2)            # up-going jj = 1..N
-    block[1][:, rows, :n] = out[:nr, :, :n][:, :, ::-1].transpose(1, 0, 2)    # down-going jj = -1..-N
+    if rows != list(range(nr)):
+        raise ValueError("azimuth rows must be 0..nr-1")                      # (both view modes of _trphi_azimuths)
+    block[0, :, :nr, :n] = out[:nr, :, n + 1:].transpose(1, 0, 2)             # up-going jj = 1..N
+    block[1, :, :nr, :n] = out[:nr, :, :n][:, :, ::-1].transpose(1, 0, 2)     # down-going jj = -1..-N
     tabs = {nm: block[0, qi] for qi, nm in enumerate(names)}
     tabs_dn = {nm: block[1, qi] for qi, nm in enumerate(names)}
     return phi_fin, theta_fin, tabs, tabs_dn

@@ -225,15 +225,17 @@ class SosContext:
             nblev = int(t_alt.numel())
             if t_tab.shape != (nb, nblev):
                 raise ValueError("tabs must be [nb][len(altabs)]")
-        prof = torch.zeros((nb, 3, lp), dtype=torch.float64, device=d)
-        zprof = torch.zeros((nb, lp), dtype=torch.float64, device=d)
-        nt = torch.zeros(nb, dtype=torch.int32, device=d)
-        iborm = torch.zeros(nb, dtype=torch.int32, device=d)
-        scal = torch.zeros((nb, 4), dtype=torch.float64, device=d)
+        # (two cleared blocks instead of seven: a band has 1-125 bins, each fill is a launch)
+        fb = torch.zeros(nb * (4 * lp + 5), dtype=torch.float64, device=d)
+        ib = torch.zeros(3 * nb, dtype=torch.int32, device=d)
+        prof = fb[:nb * 3 * lp].view(nb, 3, lp)
+        zprof = fb[nb * 3 * lp:nb * 4 * lp].view(nb, lp)
+        scal = fb[nb * 4 * lp:nb * (4 * lp + 4)].view(nb, 4)
+        nt, iborm = ib[:nb], ib[nb:2 * nb]
         jout = zz = None
         if zout != -1.0:
-            jout = torch.zeros(nb, dtype=torch.int32, device=d)
-            zz = torch.zeros(nb, dtype=torch.float64, device=d)
+            jout = ib[2 * nb:]
+            zz = fb[nb * (4 * lp + 4):]
         capi.check(capi.lib().sosgpu_profile(self._h, nb, tr, hr, ta, ha, int(absprofil), nblev, _ptr(t_alt), _ptr(t_tab),
                                              a_tronc, piz, piztr, zout, lp, _ptr(prof), _ptr(nt), _ptr(iborm),
                                              _ptr(zprof), _ptr(jout), _ptr(zz), _ptr(scal), self._stream()),

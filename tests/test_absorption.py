@@ -180,11 +180,14 @@ def test_sos_proc_ckd_vs_reference(gpu_pkg, fic, name, tmp_path):
 
 
 def test_vectorised_layer_tables_equal_the_scalar_restatement(pkg, fic):
-    """layer_tables interpolates the 49 layers of a (term, gas) pair together; it must reproduce, bit for bit, the layer-by-layer
-    form that follows COEFF_ABS_CKD statement for statement (clamps carried from gas to gas included)."""
+    """layer_tables interpolates the 49 layers of all (term, gas) pairs together on brackets kept per atmosphere; it must
+    reproduce, bit for bit, the layer-by-layer form that follows COEFF_ABS_CKD statement for statement (clamps carried from gas
+    to gas included), and so must the pair-by-pair form between the two."""
     A = pkg.absorption
     for wa, ap, h2o in ((0.762, 2, -999.), (1.0e4 / 15925.0, 1, 2.5), (1.0e4 / 15925.0, 6, -999.)):
         prep = A.prepa_absprofile(wa, 10.0, 1013.0, h2o, -999., -999., -999., ap)
         xv, rv = A.layer_tables(prep)
         xs, rs_ = A.layer_tables_scalar(prep)
         assert np.array_equal(xv, xs) and np.array_equal(rv, rs_) and (xs != 0).sum() > 100
+        xp, rp = A.layer_tables_by_pair(prep)
+        assert np.array_equal(xp, xs) and np.array_equal(rp, rs_)
