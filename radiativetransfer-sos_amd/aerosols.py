@@ -185,12 +185,17 @@ def prefetch_size_integrals(requests, batch=32):
         w = len(xmu)
         dev = torch.device("cuda", device)
         for c0 in range(0, len(keys), batch):
-            part = keys[c0:c0 + batch]
+            part, recs = [], []
+            for k in keys[c0:c0 + batch]:
+                try:
+                    recs.append(_mie_device_records(xmu, k[1], k[2], MIE_ALPHAMIN, k[3], device)[0])
+                    part.append(k)
+                except AerosolError:                       # (the call that owns this integral reports it)
+                    pass
+            if not part:
+                continue
             jobs = (capi.GranuJob * len(part))()
-            recs = []
-            for j, k in enumerate(part):
-                rec, _ = _mie_device_records(xmu, k[1], k[2], MIE_ALPHAMIN, k[3], device)
-                recs.append(rec)
+            for j, (k, rec) in enumerate(zip(part, recs)):
                 jobs[j] = capi.GranuJob(rec.data_ptr(), int(rec.shape[0]), k[4], k[5], k[6], k[7], k[8], k[3])
             stride = 3 * max(int(r.shape[0]) for r in recs) + 1
             out = torch.empty((len(part), 3 + 3 * w), dtype=torch.float64, device=dev)
@@ -731,7 +736,7 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
     ct = d["coef_tronca"]
     piztr = piz * (1. - ct / 2.) / (1. - piz * ct / 2.)
     # what SOS_PREPA_OS reads back from Aerosols.txt: E15.8 coefficients, F9.5 truncation coefficient and albedo
-    q8 = lambda a: _round_sig(a, 8)
+    q = _round_sig(np.stack([d["alpha"], d["beta"], d["gamma"], d["zeta"]]), 8)      # (element-wise: one call for the four)
     a_f, piztr_f = float("%9.5f" % ct), float("%9.5f" % piztr)
-    return dict(alpha=q8(d["alpha"]), beta=q8(d["beta"]), gamma=q8(d["gamma"]), zeta=q8(d["zeta"]), a_tronc=a_f, piztr=piztr_f,
+    return dict(alpha=q[0], beta=q[1], gamma=q[2], zeta=q[3], a_tronc=a_f, piztr=piztr_f,
                 piz=piztr_f / (1 + 0.5 * a_f * (piztr_f - 1)), kmat1=kmat1, kmat2=kmat2, coef_tronca=ct)

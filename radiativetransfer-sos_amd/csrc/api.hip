@@ -69,7 +69,8 @@ extern "C" int sosgpu_device_count(void)
 }
 
 // Device memory of the per-wavelength tables and of the entry points' temporaries comes from a process-wide pool of released
-// blocks (size classes: 256 B steps up to 4 KiB, then eighths of the leading power of two; at most 4 GiB / 1024 blocks kept).
+// blocks (size classes: 256 B steps up to 4 KiB, then eighths of the leading power of two; at most 16 GiB of the 288 / 8192 blocks kept:
+// a chunk of sos_spectrum holds 256 contexts of six blocks each, and what the pool drops is a hipFree + hipMalloc per block).
 // One sos_proc call = one context: without the pool every call pays ~10 hipMalloc + hipFree, and hipFree waits for the
 // whole device -- i.e. for the kernels of every other host thread.  A block is only returned after the work that used it has been
 // waited for (sosgpu_destroy: the context's streams; temporaries: their stream).  sosgpu_trim() empties the pool.
@@ -132,7 +133,7 @@ void mem_give(int dev, void *p, size_t cls)
         std::lock_guard<std::mutex> lk(g_mem_mutex);
         g_mem_free.push_back({p, cls, dev});
         g_mem_bytes += cls;
-        while (g_mem_free.size() > 1024 || g_mem_bytes > ((size_t)4 << 30)) {      // oldest first
+        while (g_mem_free.size() > 8192 || g_mem_bytes > ((size_t)16 << 30)) {     // oldest first
             g_mem_bytes -= g_mem_free.front().n;
             drop.push_back(g_mem_free.front());
             g_mem_free.erase(g_mem_free.begin());
@@ -360,7 +361,7 @@ double *pool_take(int dev, size_t need, size_t *got)
     if (getenv("SOSGPU_DEBUG_POOL")) fprintf(stderr, "[sosgpu pool] hipMalloc %.1f MB\n", need * 8e-6);
     if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError();
-        sosgpu_trim();                             // up to 8 GiB of kept scratch + 4 GiB of kept tables: release, retry once
+        sosgpu_trim();                             // up to 8 GiB of kept scratch + 16 GiB of kept tables: release, retry once
         (void)hipSetDevice(dev);
         if (hipMalloc((void **)&p, need * sizeof(double)) != hipSuccess) return nullptr;
     }

@@ -759,6 +759,22 @@ def _trphi_azimuths(itrphi, phios, pas_phi):
     return phis, rows, phi_fin
 
 
+def _zero_pages(shape):
+    """A large zeroed float64 array on small pages: the fixed-size (361,81) result tables of a spectrum are mostly padding that
+    is never written, and numpy asks for transparent huge pages for large blocks -- the first row written into a table would
+    then clear 2 MB."""
+    import mmap
+    nbytes = int(np.prod(shape)) * 8
+    if nbytes < (8 << 20) or not hasattr(mmap, "MADV_NOHUGEPAGE"):
+        return np.zeros(shape)
+    m = mmap.mmap(-1, nbytes)
+    try:
+        m.madvise(mmap.MADV_NOHUGEPAGE)
+    except OSError:
+        pass
+    return np.frombuffer(m, dtype=np.float64).reshape(shape)
+
+
 def _trphi_pack(n, mu, out, rows, phi_fin, block=None):
     """sosgpu_trphi's [nphi][7][W] (host array) -> PHI_FIN, THETA_FIN and the fourteen (361,81) tables.
     block: zeroed (2,7,361,81) array to fill (sos_spectrum hands out slices of one allocation per chunk of wavelengths: 3.3 MB
@@ -1398,7 +1414,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
             t4 = time.perf_counter()
             tm["trphi"] += t4 - t3
             pos, k = 0, 0
-            blocks = np.zeros((len(outs), 2, 7, 361, 81))     # the result tables of the chunk's wavelengths (views of it)
+            blocks = _zero_pages((len(outs), 2, 7, 361, 81))  # the result tables of the chunk's wavelengths (views of it)
             for gp, _, _, _ in solved:
                 for pl in gp:
                     cnt = outs[k].numel()
