@@ -491,6 +491,25 @@ def run_hyperspectral(pkg, torch, dist, world, rank, every=1):
                             parallelism="wavelengths dealt to %d rank(s) by cost, results gathered" % world))
 
 
+def hyperspectral_four_processes(args, user_queues):
+    """The hyperspectral workload with FOUR host processes sharing the GPU (`--workload hyperspectral --ranks-per-gpu 4` as a
+    child job: the wavelength partition of the multi-GPU path, gloo gather): the preparation of a wavelength is ~1.2 ms of
+    Python against ~0.1 ms of GPU time, so one interpreter per GPU leaves the card idle.  Returns the child's figures or None."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "hyperspectral", "--ranks-per-gpu", "4",
+           "--spectrum-every", str(args.spectrum_every)]
+    env = dict(os.environ)
+    if user_queues is None:
+        env.pop("GPU_MAX_HW_QUEUES", None)                  # (the child picks the queue count of its own layout)
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, env=env).stdout.decode()
+        line = [l for l in out.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        return {k: r[k] for k in ("value", "unit", "wavelengths_per_s", "seconds", "host_ms_per_wavelength",
+                                  "gpu_wait_ms_per_wavelength", "host_processes_per_gpu")}
+    except Exception as e:                                  # (the one-process figure stands on its own)
+        return dict(error=str(e)[:200])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -521,8 +540,11 @@ def main():
         return
     # sos_spectrum spreads the per-wavelength preparation kernels over HIP streams: give them hardware queues of their own (the
     # runtime's default is 4; must be set before the first GPU call of the process)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     rpg = max(1, args.ranks_per_gpu)
+    user_queues = os.environ.get("GPU_MAX_HW_QUEUES")
+    # (several host processes on one card: two queues each -- with sixteen each the card's hardware queues are oversubscribed
+    #  and every launch waits for a queue switch: 249 wavelengths/s for two processes against 1089 for four with two queues)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if rpg == 1 else "2")
     if rpg > 1 and args.workload != "hyperspectral":
         sys.exit("bench.py: --ranks-per-gpu is for --workload hyperspectral (the bin-sharded workloads fill a GPU from one rank)")
     if args.gpus * rpg > 1 and "WORLD_SIZE" not in os.environ:
@@ -539,6 +561,9 @@ def main():
     # the all-cores CPU baseline runs in child processes started BEFORE this process initialises the GPU, while the main
     # process imports torch and builds its workload (its ~12 s overlap the GPU warm-up, not the timed steps: collected first)
     cpu_procs = None
+    hyper_procs4 = None
+    if world == 1 and rank == 0 and args.workload == "headline" and not args.no_hyper and not args.no_mix:
+        hyper_procs4 = hyperspectral_four_processes(args, user_queues)         # (a child job, finished before this process uses the GPU)
     if world == 1 and rank == 0 and not args.no_cpu and args.workload == "headline":
         cpu_procs = cpu_baseline_all_cores(args.cpu_seconds)
 
@@ -595,6 +620,8 @@ def main():
                                            dict(ro=0.0, imat_surf=1))]
         if not args.no_hyper:
             res["hyperspectral"] = run_hyperspectral(pkg, torch, dist, world, rank, args.spectrum_every)
+            if hyper_procs4:
+                res["hyperspectral"]["four_host_processes"] = hyper_procs4
     if rank == 0:
         res["config"]["mean_fourier_orders"] = float(nord.mean())
         if world == 1 and not args.no_cpu:

@@ -1230,12 +1230,15 @@ def _compact_outputs(t, nrow):
     return tuple(np.ascontiguousarray(x[:nrow, :n]) if i in _TABLE_NAMES else x for i, x in enumerate(t)) + (nrow,)
 
 
-def _expand_outputs(c):
+def _expand_outputs(c, block=None):
+    """block: zeroed (14, 361, 81) array for the tables (a slice of one allocation per gather, _zero_pages)."""
     nrow = c[-1]
     out = []
+    t = 0
     for i, x in enumerate(c[:-1]):
         if i in _TABLE_NAMES:
-            full = np.zeros((361, 81))
+            full = np.zeros((361, 81)) if block is None else block[t]
+            t += 1
             full[:nrow, :x.shape[1]] = x
             out.append(full)
         else:
@@ -1250,10 +1253,11 @@ def _gather_results(results, mine, nrows, world):
     part = [(i, _compact_outputs(results[i], nrows[i])) for i in mine]
     parts = [None] * world
     dist.all_gather_object(parts, part)
-    for pr in parts:
-        for i, c in pr:
-            if results[i] is None:
-                results[i] = _expand_outputs(c)
+    todo = [(i, c) for pr in parts for i, c in pr if results[i] is None]
+    blocks = _zero_pages((len(todo), len(_TABLE_NAMES), 361, 81)) if todo else None
+    for k, (i, c) in enumerate(todo):
+        if results[i] is None:
+            results[i] = _expand_outputs(c, blocks[k])
 
 
 def spectrum_costs(kwargs_list):
