@@ -704,7 +704,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4) ? (COLS == 16 ? 3 : 2) : 1) void
         //  waves 0 and 1 but thread 0), so it is not a race; the source has no path on which a down-going row's I3 is zero
         //  there; in that build's ISA the store, its address (SGPR pair restored from VGPR lanes) and its exec mask are right
         //  and the stored register pair is one the allocator shares between xb and i3 -- where its last definition for the
-        //  down-going waves is lost was not traced through the 24 000 lines.  The shipped exit keeps I3 live into the stop
+        //  down-going waves is lost was not traced through the 24 000 lines (a build without SGPR spills into VGPR lanes,
+        //  -mllvm -amdgpu-spill-sgpr-to-vgpr=0, would isolate that mechanism: the backend refuses it for this kernel,
+        //  "unhandled SGPR spill to memory").  The shipped exit keeps I3 live into the stop
         //  test, which every instantiation needs anyway, and the hand-over is checked against the per-bin launch for ALL
         //  twelve (NW, RTWH, ZO, SURF) instantiations with several rounds: tests/test_gpu_parity.py, _ALL_VARIANTS.)
         if (spec) bn.spec_i3[((size_t)b * S1 + s) * NTH + t] = i3;
