@@ -55,6 +55,32 @@ def test_sharded_band_rccl_two_gpus(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rccl_collectives_of_the_band_reduce_on_one_rank(tmp_path):
+    """What the one-GPU box can tell about the RCCL path: a process group with backend "nccl" comes up, and the two collectives
+    of dist.all_reduce_partial (fp64 SUM of the packed band, MAX of the order counts) run on device tensors of the band's size
+    and leave a one-rank band unchanged.  (The two-rank test above needs two devices.)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "buf = torch.randn((1, 81 * 3 * 83 + 51), dtype=torch.float64, device='cuda', generator=g)\n"
+        "ref = buf.clone(); mx = buf[:, -44:-42].clone()\n"
+        "dist.all_reduce(buf, op=dist.ReduceOp.SUM); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.barrier()\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(buf, ref) and torch.equal(mx, ref[:, -44:-42])\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,world", [("ckd_h2o_o2_25bins_flatsea", 3), ("ckd_o2a_5bins", 4), ("cfg2_lnd_lambert", 2)])
 def test_sos_proc_sharded(tmp_path, case, world):
     """The drop-in under torch.distributed: run_sos.sos_proc shards the CKD bins of the band over the ranks (BASELINE config 3:
