@@ -501,7 +501,7 @@ def hyperspectral_four_processes(args, user_queues):
     if user_queues is None:
         env.pop("GPU_MAX_HW_QUEUES", None)                  # (the child picks the queue count of its own layout)
     try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=200, env=env).stdout.decode()
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, env=env).stdout.decode()
         line = [l for l in out.splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
         return {k: r[k] for k in ("value", "unit", "wavelengths_per_s", "seconds", "host_ms_per_wavelength",
@@ -563,6 +563,7 @@ def main():
     cpu_procs = None
     hyper_procs4 = None
     if world == 1 and rank == 0 and args.workload == "headline" and not args.no_hyper and not args.no_mix:
+        import torch                                   # (pages the library in for the child ranks too; no GPU call yet)
         hyper_procs4 = hyperspectral_four_processes(args, user_queues)         # (a child job, finished before this process uses the GPU)
     if world == 1 and rank == 0 and not args.no_cpu and args.workload == "headline":
         cpu_procs = cpu_baseline_all_cores(args.cpu_seconds)
