@@ -290,8 +290,14 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     const size_t o_mu = 0, o_ga = up32(o_mu + N), o_coef = up32(o_ga + N), o_fres = up32(o_coef + coef.size()),
                  o_map = up32(o_fres + fres.size()), o_vt = up32(o_map + (rowmap.size() + 1) / 2),
                  n_vt = (size_t)3 * d.ks2h * 128, n_uf = (size_t)3 * d.rtph * 64, o_uf = up32(o_vt + n_vt), n_small = o_uf + n_uf;
+    // ... followed, in the same allocation, by the tables the kernels of sosgpu_noyaux / sosgpu_set_surface_matrices fill
+    // (one pool request -- in a cold process one hipMalloc -- per context instead of six)
+    const size_t per = (size_t)2 * d.rtph * d.ks2h * 128, S1c = (size_t)d.smax + 1;
+    const size_t o_prt = up32(n_small), o_aer = up32(o_prt + S1c * 3 * (B + 1) * d.w), o_sv = up32(o_aer + S1c * per),
+                 o_gop = up32(o_sv + S1c * 4 * d.kp), n_gop = d.imat_surf ? S1c * (per / 2) : 0, o_gdir = up32(o_gop + n_gop),
+                 n_gdir = d.imat_surf ? S1c * 3 * N : 0, n_all = o_gdir + n_gdir;
     double *small = nullptr;
-    if ((rc = dev_alloc(cx, &small, n_small))) { sosgpu_destroy(cx); return rc; }
+    if ((rc = dev_alloc(cx, &small, n_all))) { sosgpu_destroy(cx); return rc; }
     static thread_local double *stage = nullptr;           // (kept for the life of the thread: 64 KB at the largest N and OS_NB)
     static thread_local size_t stage_n = 0;
     if (stage_n < o_vt) {
@@ -311,13 +317,8 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     d.rowmap = reinterpret_cast<int32_t *>(small + o_map);
     d.nwgt = nwgt;
     d.mp_vt = small + o_vt; d.mp_uf = small + o_uf;
-    const size_t per = (size_t)2 * d.rtph * d.ks2h * 128;
-    if ((rc = dev_alloc(cx, &d.prt, (size_t)(d.smax + 1) * 3 * (B + 1) * d.w)) ||
-        (rc = dev_alloc(cx, &d.mp_aer, (size_t)(d.smax + 1) * per)) ||
-        (rc = dev_alloc(cx, &d.sv, (size_t)(d.smax + 1) * 4 * d.kp))) {
-        sosgpu_destroy(cx);
-        return rc;
-    }
+    d.prt = small + o_prt; d.mp_aer = small + o_aer; d.sv = small + o_sv;
+    if (d.imat_surf) { cx->gnd_op = small + o_gop; cx->gnd_dir = small + o_gdir; }
     // The upload and the fill run on the calling thread's utility stream and are waited for here (the pinned block is reused by
     // the thread's next call): when the call returns every table is in place, whatever stream sosgpu_noyaux and the solves are
     // queued on afterwards.  (Round 2 filled on the null stream: a non-blocking caller stream does not wait for it, and a fill
