@@ -261,9 +261,9 @@ int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
  * Outputs (device): d_prof[nb][3][lp] (H, XDEL, YDEL as sosgpu_os_solve takes them), d_nt[nb] (-1: the profile needs
  * more than CTE_OS_NT = 600 levels or lp is too small -- the reference's IER = -1), d_iborm[nb], d_zprof[nb][lp],
  * d_jout[nb] / d_zz[nb] (NULL when zout = -1), d_scal[nb][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT} (the layout
- * sosgpu_aggregate takes).  The no-gas profile of the wavelength is computed on the host and uploaded first on the calling
- * thread's private stream; `stream` itself is not waited for (a second call on the same context first waits for the
- * context's earlier work).  IPROFIL = 2 (aerosol layer between two altitudes) is not implemented
+ * sosgpu_aggregate takes).  The no-gas profile of the wavelength (SOS_PROFIL.F:349-489) is made by one wavefront queued on
+ * `stream` in front of the bins' kernel; nothing is waited for (a second call on the same context from ANOTHER stream first
+ * waits for the context's earlier work).  IPROFIL = 2 (aerosol layer between two altitudes) is not implemented
  * (the reference's branch reads an unassigned Hmol(0), its output is not reproducible). */
 int  sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, double ha, int absprofil,
                     int nblev, const double *d_altabs, const double *d_tabs,

@@ -39,6 +39,7 @@ struct sosgpu_ctx {
     double *agg_partial;    // chunk partials of the large-batch aggregate
     double *scratch;        // field-in-HBM variant: grow-only per-bin scratch
     double *prof_ng;        // [4][608] no-gas profile of the wavelength (sosgpu_profile)
+    hipStream_t prof_ng_stream;   // stream of the last sosgpu_profile (the block is rewritten in stream order)
     double *gnd_op, *gnd_dir;   // packed ground-reflection operators / solar-beam columns of the surface matrices (context-owned)
     size_t scratch_doubles;
     size_t dbg_spec_i3;     // offset of the order-parallel form's I3 block in the scratch of the last solve (diagnostic)
@@ -217,6 +218,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     cx->phase = nullptr;
     cx->agg_partial = nullptr;
     cx->prof_ng = nullptr;
+    cx->prof_ng_stream = nullptr;
     cx->gnd_op = nullptr;
     cx->gnd_dir = nullptr;
     SosDev &d = cx->d;
@@ -1108,66 +1110,23 @@ extern "C" int sosgpu_land_surface(int device, const sosgpu_land *land, int n, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// SOS_PROFILE on the device.  The no-gas profile (SOS_PROFIL.F:349-489) is the same for every bin of a wavelength:
-// it is computed here on the host (O(NT * 25) exp, ~0.1 ms) and shared; the per-bin gas step runs in profile.hip.
+// SOS_PROFILE on the device (profile.hip): the no-gas profile (SOS_PROFIL.F:349-489), the same for every bin of a wavelength, by
+// one wavefront, the per-bin gas step by one wavefront per bin.
 // ---------------------------------------------------------------------------------------------
 namespace {
 const int kOsNt = 600, kOsNtMin = 100;
-const double kTcouche = (double)0.005f, kTFirst = (double)0.0002f, kDeltaZ = (double)0.05f, kToa = 120.0;
+const double kTcouche = (double)0.005f, kTFirst = (double)0.0002f;
 
-double disc_nogas(double dt, double ta, double ha, double tr, double hr, double tim1, double zmax_init)
-{
-    const double ti = tim1 + dt;                       // SOS_DISC with TG_ZLIM = 0 (SOS_PROFIL.F:1276-1325)
-    double zmax = zmax_init, zmin = 0., zmoy = 0.;
-    for (int guard = 0; guard < 4096; guard++) {
-        zmoy = (zmax + zmin) / 2.;
-        const double tz = ta * exp(-zmoy / ha) + tr * exp(-zmoy / hr) + 0.0;
-        if (fabs(ti - tz) < (double).000001f || zmoy == 0.0) break;
-        if ((ti - tz) < 0.0) zmin = zmoy; else zmax = zmoy;
-    }
-    return zmoy;
-}
-
-// returns NT_NG or -1; arrays z, h, pca, pcm of kOsNt + 1
-int profile_nogas_host(double tr, double hr, double ta, double ha, double *z, double *h, double *pca, double *pcm)
+// Level count and the two optical-depth steps of the no-gas profile (SOS_PROFIL.F:349-366): returns NT or -1 (more than
+// CTE_OS_NT levels, or no scatterer at all).  The levels themselves are placed on the device (k_profile_nogas).
+int profile_nogas_grid(double tr, double ta, double *t_first, double *t_layer)
 {
     int nt;
-    double t_first, t_layer;
     const double ttot = tr + ta;
-    if ((ttot / kOsNtMin) <= kTFirst) { nt = kOsNtMin; t_layer = ttot / nt; t_first = t_layer; }
-    else if ((ttot / kOsNtMin) < kTcouche) { nt = kOsNtMin + 1; t_first = kTFirst; t_layer = (ttot - t_first) / kOsNtMin; }
-    else { t_first = kTFirst; nt = (int)((ttot - t_first) / kTcouche); t_layer = (ttot - t_first) / nt; nt = nt + 1; }
+    if ((ttot / kOsNtMin) <= kTFirst) { nt = kOsNtMin; *t_layer = ttot / nt; *t_first = *t_layer; }
+    else if ((ttot / kOsNtMin) < kTcouche) { nt = kOsNtMin + 1; *t_first = kTFirst; *t_layer = (ttot - *t_first) / kOsNtMin; }
+    else { *t_first = kTFirst; nt = (int)((ttot - *t_first) / kTcouche); *t_layer = (ttot - *t_first) / nt; nt = nt + 1; }
     if (nt > kOsNt || !(ttot > 0.)) return -1;
-    std::vector<double> hmol(nt + 1), haer(nt + 1);
-    if (ta == 0.0) {
-        hmol[0] = 0.; hmol[1] = t_first;
-        for (int i = 2; i <= nt; i++) hmol[i] = (i - 1) * t_layer + t_first;
-        for (int i = 0; i <= nt; i++) { pcm[i] = 1.; pca[i] = 0.; haer[i] = 0.; }
-        z[0] = kToa;
-        for (int i = 1; i <= nt; i++) z[i] = hr * log(tr / hmol[i]);
-    } else {
-        z[0] = kToa; hmol[0] = 0.; haer[0] = 0.;
-        double dtau = 0., zz = kToa;
-        while (dtau < t_first) { zz = zz - kDeltaZ; dtau = tr * exp(-zz / hr) + ta * exp(-zz / ha); }
-        z[1] = zz;
-        double vr = tr * exp(-zz / hr), va = ta * exp(-zz / ha);
-        hmol[1] = vr; haer[1] = va;
-        pcm[1] = vr / dtau; pca[1] = va / dtau;
-        pcm[0] = pcm[1]; pca[0] = pca[1];
-        double hprev = dtau;
-        for (int i = 2; i <= nt - 1; i++) {
-            zz = disc_nogas(t_layer, ta, ha, tr, hr, hprev, z[1]);
-            z[i] = zz;
-            vr = tr * exp(-zz / hr); va = ta * exp(-zz / ha);
-            hmol[i] = vr; haer[i] = va; hprev = vr + va;
-            vr = vr - hmol[i - 1]; va = va - haer[i - 1];
-            pcm[i] = vr / (vr + va); pca[i] = va / (vr + va);
-        }
-        z[nt] = 0.; hmol[nt] = tr; haer[nt] = ta;
-        vr = tr - hmol[nt - 1]; va = ta - haer[nt - 1];
-        pcm[nt] = vr / (vr + va); pca[nt] = va / (vr + va);
-    }
-    for (int i = 0; i <= nt; i++) h[i] = hmol[i] + haer[i];
     return nt;
 }
 }  // namespace
@@ -1186,18 +1145,17 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;
     const int NG = 608;
-    std::vector<double> ng((size_t)4 * NG, 0.);
-    const int nt_ng = profile_nogas_host(tr, hr, ta, ha, &ng[0], &ng[NG], &ng[2 * NG], &ng[3 * NG]);
+    double t_first = 0., t_layer = 0.;
+    const int nt_ng = profile_nogas_grid(tr, ta, &t_first, &t_layer);
     if (nt_ng < 0) return SOSGPU_E_UNSUPPORTED;        // more than CTE_OS_NT levels (IER = -1 in the reference)
     if (lp <= nt_ng) return SOSGPU_E_ARG;
-    // the no-gas profile goes up on the calling thread's utility stream (waited for: `ng` is a local) -- `stream` itself is
-    // never waited for, so profiles, solve and aggregate of a wavelength queue up behind one another without a host stall
-    hipStream_t us = util_stream(cx->device);
-    if (!us) return SOSGPU_E_HIP;
+    // the no-gas profile is made on `stream` in front of the bins' kernel: nothing is waited for, so profiles, solve and aggregate
+    // of a wavelength queue up behind one another without a host stall
     if (!cx->prof_ng) { if (int rc = dev_alloc(cx, &cx->prof_ng, (size_t)4 * NG)) return rc; }
-    else HIPCHK(sync_ctx_streams(cx));                // an earlier sosgpu_profile of this context may still be reading it
-    HIPCHK(hipMemcpyAsync(cx->prof_ng, ng.data(), (size_t)4 * NG * sizeof(double), hipMemcpyHostToDevice, us));
-    HIPCHK(hipStreamSynchronize(us));
+    else if (cx->prof_ng_stream != st) HIPCHK(sync_ctx_streams(cx));    // an earlier call on another stream may still be reading it
+    cx->prof_ng_stream = st;
+    launch_profile_nogas(tr, hr, ta, ha, nt_ng, t_first, t_layer, cx->prof_ng, NG, st);
+    HIPCHK(hipGetLastError());
     ProfileArgs a;
     a.nb = nb; a.lp = lp; a.nblev = nblev; a.absprofil = d_tabs ? absprofil : 7; a.smax = cx->d.smax; a.nt_ng = nt_ng;
     a.tr = tr; a.hr = hr; a.ta = ta; a.ha = ha; a.a_tronc = a_tronc; a.piz = piz; a.piztr = piztr; a.zout = zout;

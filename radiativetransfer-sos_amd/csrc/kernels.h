@@ -57,6 +57,9 @@ struct ProfileArgs {
     int32_t *nt, *iborm, *jout;
 };
 void launch_profile(const ProfileArgs &a, hipStream_t st);
+// the no-gas profile of the wavelength into d_ng = z | h | pca | pcm, `ng` doubles each (nt + 1 <= ng used)
+void launch_profile_nogas(double tr, double hr, double ta, double ha, int nt, double t_first, double t_layer, double *d_ng, int ng,
+                          hipStream_t st);
 
 // SOS_ABSPROFILE for nb bins: ik[nb][8] 1-based term per gas, xk[8][nterm][nlev-1], ro[8][nlev-1] -> tabs[nb][nlev]
 void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro, double *d_tabs,

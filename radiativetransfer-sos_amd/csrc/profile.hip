@@ -11,9 +11,9 @@
 // device layout of sosgpu_os_solve and the text round trip (F10.5 / E15.8) is applied in registers, exactly.
 //
 // Work split: the no-gas profile (SOS_PROFIL.F:349-489) depends only on (TR,HR,TA,HA) -- identical for all bins of a
-// wavelength -- and is computed once on the host (api.hip); the gas step depends on the bin's absorption profile and
-// runs one thread per bin (the level loop is a serial recurrence: each level starts from the optical depth the
-// previous bisection actually reached).  Latency/transcendental-bound: ~NT * 25 bisection steps * 2 exp per bin, no
+// wavelength -- and is computed once, by one wavefront (k_profile_nogas, queued in front of k_profile); the gas step depends
+// on the bin's absorption profile and runs one wavefront per bin (the level loop is a serial recurrence: each level starts
+// from the optical depth the previous bisection actually reached).  Latency/transcendental-bound: ~NT * 25 bisection steps * 2 exp per bin, no
 // HBM traffic to speak of (50 doubles in, 4 * (NT+1) doubles out per bin).
 #include <algorithm>
 #include "sos_common.h"
@@ -174,6 +174,60 @@ __device__ double disc_wave(double dt, double ta, double ha, double tr, double h
 }
 
 }  // namespace
+
+// The no-gas profile of the wavelength (SOS_PROFIL.F:349-489): level altitudes by equal optical-depth steps of molecules +
+// aerosols, the shares of the two in every layer.  One wavefront, all lanes in lockstep on the same values (stores of one
+// instruction go to one address), SOS_DISC by the 64 lanes (disc_wave).  Rounds 1-2 ran this loop on the host inside
+// sosgpu_profile -- NT x 25 bisection steps x 2 exp, 0.3-0.4 ms of every wavelength of a spectrum plus a waited-for upload;
+// the level count and the two steps are closed forms of (TR, TA) and stay there (api.hip, profile_nogas_grid).
+//   z, h, pca, pcm [nt + 1]: altitude, cumulative optical depth, aerosol and molecular share of the layer ending at the level
+__global__ __launch_bounds__(64) void k_profile_nogas(double tr, double hr, double ta, double ha, int nt, double t_first,
+                                                      double t_layer, double *__restrict__ z, double *__restrict__ h,
+                                                      double *__restrict__ pca, double *__restrict__ pcm)
+{
+    const double TOA = 120.0, DELTA_Z = (double)0.05f;
+    if (ta == 0.0) {                                             // molecules only: closed form (SOS_PROFIL.F:367-392)
+        for (int i = threadIdx.x; i <= nt; i += 64) {
+            const double hm = i == 0 ? 0. : (i == 1 ? t_first : (i - 1) * t_layer + t_first);
+            pcm[i] = 1.; pca[i] = 0.;
+            z[i] = i == 0 ? TOA : hr * log(tr / hm);
+            h[i] = hm + 0.;
+        }
+        return;
+    }
+    GasProf g;
+    g.n = 0; g.alt = nullptr; g.tab = nullptr;                   // (never read: TG_ZLIM = 0 below)
+    double dtau = 0., zz = TOA;
+    while (dtau < t_first) { zz = zz - DELTA_Z; dtau = tr * exp(-zz / hr) + ta * exp(-zz / ha); }
+    double vr = tr * exp(-zz / hr), va = ta * exp(-zz / ha);
+    double hmol_p = vr, haer_p = va;
+    const double z1 = zz;
+    z[0] = TOA; h[0] = 0.;
+    z[1] = zz; h[1] = vr + va;
+    pcm[1] = vr / dtau; pca[1] = va / dtau;
+    pcm[0] = pcm[1]; pca[0] = pca[1];
+    double hprev = dtau;
+    for (int i = 2; i <= nt - 1; i++) {
+        zz = disc_wave(t_layer, ta, ha, tr, hr, g, hprev, z1, 0.0, 0.0);
+        z[i] = zz;
+        vr = tr * exp(-zz / hr); va = ta * exp(-zz / ha);
+        const double hm = vr, hae = va;
+        hprev = vr + va;
+        h[i] = hprev;
+        vr = vr - hmol_p; va = va - haer_p;
+        pcm[i] = vr / (vr + va); pca[i] = va / (vr + va);
+        hmol_p = hm; haer_p = hae;
+    }
+    z[nt] = 0.; h[nt] = tr + ta;
+    vr = tr - hmol_p; va = ta - haer_p;
+    pcm[nt] = vr / (vr + va); pca[nt] = va / (vr + va);
+}
+
+void launch_profile_nogas(double tr, double hr, double ta, double ha, int nt, double t_first, double t_layer, double *d_ng, int ng,
+                          hipStream_t st)
+{
+    k_profile_nogas<<<1, 64, 0, st>>>(tr, hr, ta, ha, nt, t_first, t_layer, d_ng, d_ng + ng, d_ng + 2 * ng, d_ng + 3 * ng);
+}
 
 // One thread per bin, `bpw` bins per wavefront.  The work of a bin is a long serial chain (latency-bound) and very ragged
 // (NT 100...600, bisection depth varies), so a wavefront is deliberately left mostly EMPTY: with few bins per wave the

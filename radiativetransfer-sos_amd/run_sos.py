@@ -847,6 +847,22 @@ def _size_integral_requests(kw, aer_phase, device):
         return []
 
 
+# Host time of the segments of _prepare, summed over the calls (seconds; filled when SOS_PREPARE_SEGMENTS is set -- diagnostic of
+# scripts/hyperspectral_bench.py): segment name -> time since the previous mark of the same call.
+PREPARE_SEGMENTS = collections.OrderedDict() if os.environ.get("SOS_PREPARE_SEGMENTS") else None
+_SEG_LAST = [0.0]
+
+
+def _seg(name):
+    if PREPARE_SEGMENTS is None:
+        return
+    import time
+    t = time.perf_counter()
+    if name is not None:
+        PREPARE_SEGMENTS[name] = PREPARE_SEGMENTS.get(name, 0.0) + t - _SEG_LAST[0]
+    _SEG_LAST[0] = t
+
+
 def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     """Everything of one SOS_PROC call up to the CKD bin loop (SOS_PROC.F:1310-3458): parameter checks, SOS_ANGLES,
     SOS_AEROSOLS, SOS_SURFACE, SOS_PREPA_ABSPROFILE, SOS_PREPA_OS, and the profiles of every bin of the band on the device
@@ -855,6 +871,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     whole band stays on this rank (sos_spectrum distributes wavelengths, not bins).
     aer_stream: HIP stream (torch.cuda.Stream) for the aerosol step, whose device calls are host-synchronous -- sos_spectrum keeps
     them off the streams its asynchronous work is queued on."""
+    _seg(None)
     missing = [k for k in SOS_PROC_KWARGS if k not in kw]
     if missing:
         raise TypeError("sos_proc() missing keyword arguments: %s" % ", ".join(missing))
@@ -897,6 +914,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
         raise SosProcError("-SOS.View.Dphi must be defined for -SOS.View 2")
     igmax = CTE_DEFAULT_IGMAX if p["igmax"] == _I else int(p["igmax"])
 
+    _seg('checks')
     # --- SOS_ANGLES (SOS_PROC.F:2738)
     nb_lum = CTE_DEFAULT_NBMU_LUM if p["nbmu_gauss_lum"] == _I else int(p["nbmu_gauss_lum"])
     nb_mie = CTE_DEFAULT_NBMU_MIE if p["nbmu_gauss_mie"] == _I else int(p["nbmu_gauss_mie"])
@@ -909,6 +927,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     mu, ga, n0, ind_ang = angles(nb_lum, p["tetas"], p["ficangles_user_lum"])
     n = len(mu)
 
+    _seg('angles')
     # --- aerosols: none, a user Aerosols.txt (-AER.UserFile, SOS_PROC.F:2883-2934: SOS_AEROSOLS is not run, the file
     # is read by SOS_PREPA_OS.F:666-700), or a given expansion (stands for SOS_AEROSOLS -> Aerosols.txt)
     coef_tronca_out = None
@@ -949,6 +968,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
         if iprofil == 1 and p["ha"] == _D:
             raise SosProcError("-AP.AerHS.HA must be defined")
 
+    _seg('aerosols')
     # --- molecular optical thickness (SOS_PROC.F:3331-3351)
     tr = p["tr"]
     if tr == _D:
@@ -979,6 +999,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     if mode_ckd not in (1, 2):
         raise SosProcError("-SOS.AbsModeCKD must be 1 or 2")
 
+    _seg('gas tables')
     # --- surface (SOS_PREPA_OS.F:479-497)
     isurf = int(p["isurf"])
     igli, ifresnel, imat = int(isurf == 1), int(isurf == 2), int(isurf == 1 or isurf >= 3)
@@ -1022,9 +1043,11 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     if rsurf is not None and iborm < os_nb:
         rsurf = rsurf[:iborm + 1].contiguous()
 
+    _seg('surface')
     ctx = SosContext(mu, ga, n0, alpha, beta, gamma, zeta, iborm_max=iborm, ro=p["rho"], imat_surf=imat,
                      ifresnel=ifresnel, ind_surf=p["surf_ind"] if isurf in (1, 2) or isurf >= 4 else 1.34, ron=MDF_DEFAULT,
                      ipolar=int(p["ipolar"]), igmax=igmax, rsurf=rsurf, device=device)
+    _seg('context')
     pl = _Plan()
     pl.p, pl.ctx, pl.device = p, ctx, device
     pl.n, pl.mu, pl.ga, pl.n0, pl.ind_ang = n, mu, ga, n0, ind_ang
@@ -1040,8 +1063,8 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
         tabs_flux = None                              # TAUABS of the band's last bin (Flux file): host array or [.][nlev] device tensor
         if not use_gas and iprofil == 1:
             # the single no-gas profile of the wavelength: SOS_PROFILE, the PROFIL-file round trip, the rescale, IBORM and the
-            # output level all inside sosgpu_profile (its host half computes the no-gas profile in C++; the Python restatement
-            # profile_nogas costs 2-3 ms of a 7 ms call and stays as the checker of tests/test_profile.py)
+            # output level all inside sosgpu_profile (the Python restatement profile_nogas costs 2-3 ms and stays as the checker
+            # of tests/test_profile.py)
             try:
                 bins = ctx.make_profiles(1, tr, p["hr"], ta, ha, None, None, a_tronc=a_tronc, piz=piz, piztr=piztr, zout=zout,
                                          absprofil=7)
@@ -1101,6 +1124,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
     except BaseException:
         ctx.close()
         raise
+    _seg('profiles')
     pl.bins, pl.aik, pl.band_sharded, pl.tabs_flux = bins, aik, band_sharded, tabs_flux
     return pl
 
@@ -1337,103 +1361,114 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     main_st = torch.cuda.current_stream(dev)
     side = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(prep_streams)))]
     aer_st = torch.cuda.Stream(device=dev)
-    for c0 in range(0, len(mine), max(1, int(chunk))):
-        idx = mine[c0:c0 + max(1, int(chunk))]
-        plans = []
-        try:
-            t0 = time.perf_counter()
-            # the preparation of wavelength k queues its device work (source operators, absorption and level profiles of its
-            # bins: latency-bound kernels of 0.1-2 ms on a few wavefronts) on side stream k mod n: the wavelengths overlap on the
-            # device, and the launches below wait for all of them
-            for st in side + [aer_st]:
-                st.wait_stream(main_st)
-            # the size-distribution integrals of the chunk's wavelengths, queued ahead (aerosols.prefetch_size_integrals)
-            reqs = []
-            for i in idx:
-                reqs += _size_integral_requests(kwargs_list[i], aer_phases[i], device)
-            if reqs:
-                with torch.cuda.stream(aer_st):
-                    _aer.prefetch_size_integrals(reqs)
-            for k, i in enumerate(idx):
-                with torch.cuda.stream(side[k % len(side)]):
-                    pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
-                if debug:
-                    torch.cuda.synchronize(dev)
-                    print("[sos_spectrum] prepared", i, flush=True)
-                pl.writes_files = True
-                pl.index = i
-                plans.append(pl)
-            for st in side:
-                main_st.wait_stream(st)
-            t1 = time.perf_counter()
-            tm["prepare"] += t1 - t0
-            # --- groups of wavelengths one launch can cover
-            groups = collections.OrderedDict()
-            single = []
-            for pl in plans:
-                b = pl.bins
-                if pl.tdifmug is not None or b["nb"] == 0 or not isinstance(b.get("scal"), torch.Tensor):
-                    single.append(pl)
-                    continue
-                key = (pl.n, pl.ctx.smax, pl.ctx.os_nb, bool(pl.ctx._rsurf is not None), b["lp"], b["jout"] is not None)
-                groups.setdefault(key, []).append(pl)
-            solved = []                       # (plans, rec [nw][S][3][W], scal [nw][10+N]) device tensors
-            for key, gp in groups.items():
-                if len(gp) == 1:
-                    single.append(gp[0])
-                    continue
-                table = ContextTable([pl.ctx for pl in gp])
-                bins, cob, seg = concat_bins([pl.bins for pl in gp])
-                aik = torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])).to(dev)
-                if debug:
-                    print("[sos_spectrum] group", key, "wavelengths", [pl.index for pl in gp], "bins", bins["nb"], flush=True)
-                rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)
-                if debug:
-                    torch.cuda.synchronize(dev)
-                    print("[sos_spectrum]   done", flush=True)
-                solved.append((gp, rec, scal, table))
-            for pl in single:
-                out = pl.ctx.solve(pl.bins, pl.ctx.alloc_outputs(pl.bins["nb"], zero=False))
-                rec, scal = pl.ctx.aggregate(out, pl.aik, scal=pl.bins.get("scal"), tdifmug=pl.tdifmug)
-                solved.append(([pl], rec, scal, None))
-            t2 = time.perf_counter()
-            tm["solve_launch"] += t2 - t1
-            # --- one copy of all band scalars (waits for the solves), then every azimuth recomposition back to back
-            scal_all = torch.cat([s.reshape(-1) for _, _, s, _ in solved]).cpu().numpy()
-            t3 = time.perf_counter()
-            tm["wait"] += t3 - t2
-            outs, pos = [], 0
-            for gp, rec, scal, _ in solved:
-                sw = scal.shape[1]
-                fin = _dist.finish_scalars(scal_all[pos:pos + len(gp) * sw].reshape(len(gp), sw))
-                pos += len(gp) * sw
-                for g, pl in enumerate(gp):
-                    if fin["min_orders"][g] < 0:
-                        raise SosProcError("SOS_OS: wavelength %d (%r microns) holds a malformed bin (NT outside 1..CTE_OS_NT or "
-                                           "IBORM out of range)" % (pl.index, pl.p["wa_simu"]), ier=-1)
-                    pl.fin, pl.g, pl.rec0 = fin, g, rec[g]
-                    outs.append(_trphi_launch(pl, rec[g], int(fin["n_orders"][g]), float(fin["ttot_tronc"][g]),
-                                              float(fin["tauout"][g])))
-            flat = torch.cat([o.reshape(-1) for o in outs]).cpu().numpy()
-            t4 = time.perf_counter()
-            tm["trphi"] += t4 - t3
-            pos, k = 0, 0
-            blocks = _zero_pages((len(outs), 2, 7, 361, 81))  # the result tables of the chunk's wavelengths (views of it)
-            for gp, _, _, _ in solved:
-                for pl in gp:
-                    cnt = outs[k].numel()
-                    results[pl.index] = _finish(pl, flat[pos:pos + cnt].reshape(outs[k].shape), pl.rec0, pl.fin, pl.g, blocks[k])
-                    nrows[pl.index] = len(pl.rows)
-                    pos += cnt
-                    k += 1
-            tm["finish"] += time.perf_counter() - t4
-        finally:
-            _aer.drop_prefetched_size_integrals()
-            for st in side + [aer_st]:
-                st.synchronize()
-            main_st.synchronize()                             # the table launches read every context's operators
-            for pl in plans:
-                pl.ctx.close()
+    # The cyclic garbage collector is paused for the pass: a spectrum allocates tens of container objects per wavelength next to
+    # a growing list of result tuples, and the collections this triggers re-walk the results again and again (SOS_SPECTRUM_KEEP_GC=1
+    # leaves the collector alone).  Nothing here relies on it: contexts are closed explicitly, tensors are freed by reference count.
+    import gc
+    pause_gc = gc.isenabled() and not os.environ.get("SOS_SPECTRUM_KEEP_GC")
+    if pause_gc:
+        gc.disable()
+    try:
+        for c0 in range(0, len(mine), max(1, int(chunk))):
+            idx = mine[c0:c0 + max(1, int(chunk))]
+            plans = []
+            try:
+                t0 = time.perf_counter()
+                # the preparation of wavelength k queues its device work (source operators, absorption and level profiles of its
+                # bins: latency-bound kernels of 0.1-2 ms on a few wavefronts) on side stream k mod n: the wavelengths overlap on the
+                # device, and the launches below wait for all of them
+                for st in side + [aer_st]:
+                    st.wait_stream(main_st)
+                # the size-distribution integrals of the chunk's wavelengths, queued ahead (aerosols.prefetch_size_integrals)
+                reqs = []
+                for i in idx:
+                    reqs += _size_integral_requests(kwargs_list[i], aer_phases[i], device)
+                if reqs:
+                    with torch.cuda.stream(aer_st):
+                        _aer.prefetch_size_integrals(reqs)
+                for k, i in enumerate(idx):
+                    with torch.cuda.stream(side[k % len(side)]):
+                        pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
+                    if debug:
+                        torch.cuda.synchronize(dev)
+                        print("[sos_spectrum] prepared", i, flush=True)
+                    pl.writes_files = True
+                    pl.index = i
+                    plans.append(pl)
+                for st in side:
+                    main_st.wait_stream(st)
+                t1 = time.perf_counter()
+                tm["prepare"] += t1 - t0
+                # --- groups of wavelengths one launch can cover
+                groups = collections.OrderedDict()
+                single = []
+                for pl in plans:
+                    b = pl.bins
+                    if pl.tdifmug is not None or b["nb"] == 0 or not isinstance(b.get("scal"), torch.Tensor):
+                        single.append(pl)
+                        continue
+                    key = (pl.n, pl.ctx.smax, pl.ctx.os_nb, bool(pl.ctx._rsurf is not None), b["lp"], b["jout"] is not None)
+                    groups.setdefault(key, []).append(pl)
+                solved = []                       # (plans, rec [nw][S][3][W], scal [nw][10+N]) device tensors
+                for key, gp in groups.items():
+                    if len(gp) == 1:
+                        single.append(gp[0])
+                        continue
+                    table = ContextTable([pl.ctx for pl in gp])
+                    bins, cob, seg = concat_bins([pl.bins for pl in gp])
+                    aik = torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])).to(dev)
+                    if debug:
+                        print("[sos_spectrum] group", key, "wavelengths", [pl.index for pl in gp], "bins", bins["nb"], flush=True)
+                    rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)
+                    if debug:
+                        torch.cuda.synchronize(dev)
+                        print("[sos_spectrum]   done", flush=True)
+                    solved.append((gp, rec, scal, table))
+                for pl in single:
+                    out = pl.ctx.solve(pl.bins, pl.ctx.alloc_outputs(pl.bins["nb"], zero=False))
+                    rec, scal = pl.ctx.aggregate(out, pl.aik, scal=pl.bins.get("scal"), tdifmug=pl.tdifmug)
+                    solved.append(([pl], rec, scal, None))
+                t2 = time.perf_counter()
+                tm["solve_launch"] += t2 - t1
+                # --- one copy of all band scalars (waits for the solves), then every azimuth recomposition back to back
+                scal_all = torch.cat([s.reshape(-1) for _, _, s, _ in solved]).cpu().numpy()
+                t3 = time.perf_counter()
+                tm["wait"] += t3 - t2
+                outs, pos = [], 0
+                for gp, rec, scal, _ in solved:
+                    sw = scal.shape[1]
+                    fin = _dist.finish_scalars(scal_all[pos:pos + len(gp) * sw].reshape(len(gp), sw))
+                    pos += len(gp) * sw
+                    for g, pl in enumerate(gp):
+                        if fin["min_orders"][g] < 0:
+                            raise SosProcError("SOS_OS: wavelength %d (%r microns) holds a malformed bin (NT outside 1..CTE_OS_NT or "
+                                               "IBORM out of range)" % (pl.index, pl.p["wa_simu"]), ier=-1)
+                        pl.fin, pl.g, pl.rec0 = fin, g, rec[g]
+                        outs.append(_trphi_launch(pl, rec[g], int(fin["n_orders"][g]), float(fin["ttot_tronc"][g]),
+                                                  float(fin["tauout"][g])))
+                flat = torch.cat([o.reshape(-1) for o in outs]).cpu().numpy()
+                t4 = time.perf_counter()
+                tm["trphi"] += t4 - t3
+                pos, k = 0, 0
+                blocks = _zero_pages((len(outs), 2, 7, 361, 81))  # the result tables of the chunk's wavelengths (views of it)
+                for gp, _, _, _ in solved:
+                    for pl in gp:
+                        cnt = outs[k].numel()
+                        results[pl.index] = _finish(pl, flat[pos:pos + cnt].reshape(outs[k].shape), pl.rec0, pl.fin, pl.g, blocks[k])
+                        nrows[pl.index] = len(pl.rows)
+                        pos += cnt
+                        k += 1
+                tm["finish"] += time.perf_counter() - t4
+            finally:
+                _aer.drop_prefetched_size_integrals()
+                for st in side + [aer_st]:
+                    st.synchronize()
+                main_st.synchronize()                             # the table launches read every context's operators
+                for pl in plans:
+                    pl.ctx.close()
+    finally:
+        if pause_gc:
+            gc.enable()
     if timings is not None:
         timings.update(tm)
     if world > 1 and gather:

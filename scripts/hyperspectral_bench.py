@@ -71,12 +71,17 @@ def main():
     same = all(np.array_equal(np.asarray(x), np.asarray(y)) for s1, s2 in zip(seq, spec) for x, y in zip(s1, s2))
     same_many = all(np.array_equal(np.asarray(x), np.asarray(y)) for s1, s2 in zip(seq, many) for x, y in zip(s1, s2))
     print("    outputs identical to the plain loop, bit for bit: sos_spectrum %s, sos_proc_many %s" % (same, same_many), flush=True)
+    if rs.PREPARE_SEGMENTS is not None:
+        rs.PREPARE_SEGMENTS.clear()
     tm = {}
     t0 = time.perf_counter()
     rs.sos_spectrum(kws, timings=tm, chunk=a.chunk)
     dt = time.perf_counter() - t0
     print("(c) sos_spectrum, FULL      : %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s, %8.1f bins/s" % (len(kws), nb, dt, len(kws) / dt, nb / dt))
     print("    host phases per wavelength (ms): " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in tm.items()), flush=True)
+    if rs.PREPARE_SEGMENTS:                                  # SOS_PREPARE_SEGMENTS=1: where the preparation spends its host time
+        print("    prepare, by segment (ms)       : " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in rs.PREPARE_SEGMENTS.items()),
+              flush=True)
     if a.profile:
         pr = cProfile.Profile()
         pr.enable()
