@@ -174,8 +174,32 @@ static hipStream_t util_stream(int device)
 {
     static thread_local hipStream_t st[16] = {nullptr};
     if (device < 0 || device >= 16) return nullptr;
-    if (!st[device] && hipStreamCreateWithFlags(&st[device], hipStreamNonBlocking) != hipSuccess) st[device] = nullptr;
+    if (!st[device]) {
+        // highest priority: the runtime maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES), in order per queue, and a
+        // host framework may have created dozens of streams (torch: 32 per priority) -- at normal priority this stream then shares
+        // a queue with caller streams, and its 20 us copies wait behind their kernels (0.4 ms per sosgpu_create inside
+        // sos_spectrum, whose side streams run 1-2 ms profile kernels).  High-priority streams have hardware queues of their own.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        if (hipStreamCreateWithPriority(&st[device], hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&st[device], hipStreamNonBlocking) != hipSuccess) st[device] = nullptr;
+        }
+    }
     return st[device];
+}
+
+// Wait for the (short) work just queued on a utility stream.  hipStreamSynchronize blocks the thread on an interrupt once its
+// spin window is over -- with kernels of other streams in flight that costs 0.3-0.4 ms of wake-up latency for a 20 us copy
+// (measured inside sos_spectrum: sosgpu_create 0.41 ms against 0.03 ms on an idle device) -- so poll the stream first.
+static hipError_t wait_short(hipStream_t us)
+{
+    for (int i = 0; i < 4000; i++) {
+        const hipError_t q = hipStreamQuery(us);
+        if (q == hipSuccess) return hipSuccess;
+        if (q != hipErrorNotReady) return q;
+    }
+    return hipStreamSynchronize(us);
 }
 
 static void note_stream(sosgpu_ctx *cx, hipStream_t st)
@@ -327,7 +351,7 @@ extern "C" int sosgpu_create(sosgpu_ctx **out, int device, const sosgpu_wave *wv
     // could land on top of the molecular operator sosgpu_noyaux had already packed.)
     if (hipMemcpyAsync(small, stage, o_vt * sizeof(double), hipMemcpyHostToDevice, us) != hipSuccess ||
         hipMemsetAsync(small + o_vt, 0, (n_small - o_vt) * sizeof(double), us) != hipSuccess ||
-        hipStreamSynchronize(us) != hipSuccess) {
+        wait_short(us) != hipSuccess) {
         g_last_hip = (int)hipGetLastError();
         sosgpu_destroy(cx);
         return SOSGPU_E_HIP;

@@ -855,12 +855,18 @@ _SEG_LAST = [0.0]
 
 def _seg(name):
     if PREPARE_SEGMENTS is None:
-        return
+        return True
     import time
     t = time.perf_counter()
     if name is not None:
         PREPARE_SEGMENTS[name] = PREPARE_SEGMENTS.get(name, 0.0) + t - _SEG_LAST[0]
     _SEG_LAST[0] = t
+    return True
+
+
+if PREPARE_SEGMENTS is not None:
+    from . import solver as _solver_mod
+    _solver_mod.SEG = _seg
 
 
 def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
@@ -1309,7 +1315,7 @@ def spectrum_costs(kwargs_list):
     return costs
 
 
-def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None, prep_streams=8):
+def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None, prep_streams=16):
     """A spectrum of sos_proc calls -- one per wavelength, as the reference issues them one after the other
     (binding/run_sos.py:640-695; the bin loop of each is SOS_PROC.F:3459-3594) -- as ONE pass over the GPU:
 
@@ -1335,11 +1341,13 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     aer_phases: optional list parallel to kwargs_list of `aer_phase` dictionaries (see sos_proc) or None.
     timings: optional dict, filled with host-side phase times in seconds (prepare, solve_launch, wait, trphi, finish).
     prep_streams: HIP streams the per-wavelength preparation kernels are spread over (export GPU_MAX_HW_QUEUES=16 to give them
-    hardware queues of their own, solver.solve_many)."""
+    hardware queues of their own, solver.solve_many).  The preparation kernels of one wavelength are a serial chain of about
+    3 ms on a few wavefronts (level placement of the no-gas profile and of every bin: bisections), so the device side alone
+    sustains prep_streams / 3 ms wavelengths per second: 16 streams keep it ahead of a host that spends 0.6 ms per wavelength."""
     import time
     import torch
     from . import capi
-    from .solver import ContextTable, SosBinError, concat_bins, solve_spectrum
+    from .solver import ContextTable, SosBinError, _upload, concat_bins, solve_spectrum
     from . import dist as _dist
     from . import aerosols as _aer
     capi.lib()
@@ -1416,7 +1424,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                         continue
                     table = ContextTable([pl.ctx for pl in gp])
                     bins, cob, seg = concat_bins([pl.bins for pl in gp])
-                    aik = torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])).to(dev)
+                    aik = _upload(torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])), dev)
                     if debug:
                         print("[sos_spectrum] group", key, "wavelengths", [pl.index for pl in gp], "bins", bins["nb"], flush=True)
                     rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)

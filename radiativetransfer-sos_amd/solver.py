@@ -74,6 +74,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+SEG = None          # run_sos._seg when SOS_PREPARE_SEGMENTS is set (host-time diagnostic), else None
+
+
 class SosContext:
     """Everything SOS_OS needs that does not depend on the CKD bin (angles, phase-matrix expansion,
     surface), resident on one GPU, with the Fourier kernels of every order precomputed
@@ -103,9 +106,11 @@ class SosContext:
         self._h = C.c_void_p()
         L = capi.lib()
         dp = lambda a: a.ctypes.data_as(C.c_void_p)
+        SEG and SEG("context: python")
         capi.check(L.sosgpu_create(C.byref(self._h), self.device.index or 0, C.byref(wv), dp(self.mu), dp(self.ga),
                                    dp(coefs[0]), dp(coefs[1]), dp(coefs[2]), dp(coefs[3]), self.smax),
                    "sosgpu_create")
+        SEG and SEG("context: sosgpu_create")
         self._rsurf = None
         if int(imat_surf) == 1:
             if rsurf is None:
@@ -119,7 +124,9 @@ class SosContext:
             self._rsurf = r               # kept alive: the packing below is only queued
             capi.check(L.sosgpu_set_surface_matrices_async(self._h, _ptr(r), self._stream()),
                        "sosgpu_set_surface_matrices_async")
+            SEG and SEG("context: surface matrices")
         self.noyaux()
+        SEG and SEG("context: sosgpu_noyaux")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

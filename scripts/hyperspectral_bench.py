@@ -7,6 +7,7 @@ Measures, on one GPU: (a) the plain loop of run_sos.sos_proc calls (what the ref
 (b) run_sos.sos_proc_many (host threads + streams), (c) run_sos.sos_spectrum (one launch per kernel variant), with the host
 phases of (c) and, with --profile, a cProfile of it.  --n limits the spectrum to every k-th interval."""
 import argparse, cProfile, importlib, io, os, pstats, sys, tempfile, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # hardware queues for the side streams of sos_spectrum (runtime default: 4)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -39,6 +40,7 @@ def main():
     ap.add_argument("--loop", type=int, default=120, help="wavelengths timed in the plain sos_proc loop / sos_proc_many")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=16, help="side streams of sos_spectrum (prep_streams)")
     a = ap.parse_args()
     import torch
     pkg = importlib.import_module("radiativetransfer-sos_amd")
@@ -75,7 +77,7 @@ def main():
         rs.PREPARE_SEGMENTS.clear()
     tm = {}
     t0 = time.perf_counter()
-    rs.sos_spectrum(kws, timings=tm, chunk=a.chunk)
+    rs.sos_spectrum(kws, timings=tm, chunk=a.chunk, prep_streams=a.streams)
     dt = time.perf_counter() - t0
     print("(c) sos_spectrum, FULL      : %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s, %8.1f bins/s" % (len(kws), nb, dt, len(kws) / dt, nb / dt))
     print("    host phases per wavelength (ms): " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in tm.items()), flush=True)
