@@ -542,9 +542,10 @@ def main():
     # runtime's default is 4; must be set before the first GPU call of the process)
     rpg = max(1, args.ranks_per_gpu)
     user_queues = os.environ.get("GPU_MAX_HW_QUEUES")
-    # (several host processes on one card: two queues each -- with sixteen each the card's hardware queues are oversubscribed
-    #  and every launch waits for a queue switch: 249 wavelengths/s for two processes against 1089 for four with two queues)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if rpg == 1 else "2")
+    # (several host processes on one card share about sixteen hardware queues: beyond that the card's queues are oversubscribed
+    #  and every launch waits for a queue switch -- four processes: 1598 / 2306 / 2024 / 1363 wavelengths/s with 2 / 4 / 6 / 8
+    #  queues each, profiles/r03_hyperspectral.txt)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(2, 16 // rpg)))
     if rpg > 1 and args.workload != "hyperspectral":
         sys.exit("bench.py: --ranks-per-gpu is for --workload hyperspectral (the bin-sharded workloads fill a GPU from one rank)")
     if args.gpus * rpg > 1 and "WORLD_SIZE" not in os.environ:
