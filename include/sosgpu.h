@@ -11,6 +11,8 @@
  *     until the queued work has run;
  *   - host-synchronous entry points without a stream argument (sosgpu_create, sosgpu_set_surface_matrices,
  *     sosgpu_noyaux_fetch, sosgpu_os_flops) move their data on a private non-blocking stream of the calling host thread
+ *     (created at the highest stream priority: the runtime maps streams onto a few hardware queues, in order per queue,
+ *     and at normal priority these short copies would wait behind the kernels of whatever caller stream shares the queue)
  *     and wait for that stream only; the last two first wait for the streams THIS context's work was queued on.  They
  *     write only memory the library owns (never a caller's buffer, which the caller's other queued work may still be
  *     using), and what they wrote is complete on return, so work queued afterwards on any stream sees it;
