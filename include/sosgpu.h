@@ -264,14 +264,24 @@ int  sosgpu_last_solve_ms(sosgpu_ctx *cx, float *ms);
  * more than CTE_OS_NT = 600 levels or lp is too small -- the reference's IER = -1), d_iborm[nb], d_zprof[nb][lp],
  * d_jout[nb] / d_zz[nb] (NULL when zout = -1), d_scal[nb][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT} (the layout
  * sosgpu_aggregate takes).  The no-gas profile of the wavelength (SOS_PROFIL.F:349-489) is made by one wavefront queued on
- * `stream` in front of the bins' kernel; nothing is waited for (a second call on the same context from ANOTHER stream first
+ * `stream` in front of the bins' kernel, or taken from d_nogas (sosgpu_profile_nogas below); nothing is waited for (a second call on the same context from ANOTHER stream first
  * waits for the context's earlier work).  IPROFIL = 2 (aerosol layer between two altitudes) is not implemented
  * (the reference's branch reads an unassigned Hmol(0), its output is not reproducible). */
 int  sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, double ta, double ha, int absprofil,
                     int nblev, const double *d_altabs, const double *d_tabs,
                     double a_tronc, double piz, double piztr, double zout, int lp,
                     double *d_prof, int32_t *d_nt, int32_t *d_iborm, double *d_zprof,
-                    int32_t *d_jout, double *d_zz, double *d_scal, void *stream);
+                    int32_t *d_jout, double *d_zz, double *d_scal, const double *d_nogas, void *stream);
+
+/* Head start for sosgpu_profile (optional).  The level placement of a wavelength's no-gas profile is a serial chain of about a
+ * millisecond on one wavefront and needs (tr, hr, ta, ha) only: a driver can queue it here as soon as it knows them -- before it
+ * has the gas tables, the surface or even the context of the wavelength -- and hand the block to sosgpu_profile as d_nogas
+ * (NULL there: sosgpu_profile queues the same kernel itself, in front of the bins' kernel).
+ *   d_nogas[4][SOSGPU_NOGAS_LEVELS] (DEVICE, caller-owned): altitude, optical depth, aerosol and molecular share of each level;
+ *   must be complete, or queued on the same stream, when sosgpu_profile runs, and stay allocated until that work has run.
+ * Asynchronous on `stream`.  SOSGPU_E_UNSUPPORTED: more than CTE_OS_NT levels (the reference's IER = -1). */
+#define SOSGPU_NOGAS_LEVELS 608
+int  sosgpu_profile_nogas(int device, double tr, double hr, double ta, double ha, double *d_nogas, void *stream);
 
 /* Replaces the per-bin calls `CALL SOS_ABSPROFILE` of the CKD loop (SOS_PROC.F:3494; src/SOS_ABSPROFILE.F:184, core :325-371)
  * for nb bins at once.  The coefficient of a gas depends on the gas, the exponential term and the layer only, so the host

@@ -15,12 +15,13 @@ EXPORTS = [
     "sosgpu_strerror", "sosgpu_last_hip_error", "sosgpu_device_count", "sosgpu_version",
     "sosgpu_create", "sosgpu_destroy", "sosgpu_set_surface_matrices", "sosgpu_set_surface_matrices_async", "sosgpu_noyaux",
     "sosgpu_noyaux_fetch", "sosgpu_os_solve", "sosgpu_aggregate", "sosgpu_ctx_bytes",
-    "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
+    "sosgpu_os_flops", "sosgpu_last_solve_ms", "sosgpu_profile", "sosgpu_profile_nogas", "sosgpu_glitter", "sosgpu_mat_fresnel_host", "sosgpu_trphi",
     "sosgpu_debug_phase_buffer", "sosgpu_debug_scratch", "sosgpu_comm_unique_id", "sosgpu_comm_init_rank", "sosgpu_comm_destroy",
     "sosgpu_pack", "sosgpu_unpack", "sosgpu_reduce", "sosgpu_absprofile", "sosgpu_land_surface", "sosgpu_mie", "sosgpu_granu",
     "sosgpu_granu_batch",
     "sosgpu_ctx_table_entry_bytes", "sosgpu_ctx_table", "sosgpu_os_solve_multi", "sosgpu_trim",
 ]
+NOGAS_LEVELS = 608     # SOSGPU_NOGAS_LEVELS
 SCAL_BASE = 10          # SOSGPU_SCAL_BASE: scalar block of sosgpu_aggregate = SCAL_BASE + N doubles
 
 
@@ -123,7 +124,9 @@ def lib():
         L.sosgpu_ctx_bytes.argtypes = [vp]
         L.sosgpu_profile.restype = i32
         L.sosgpu_profile.argtypes = [vp, i32, dbl, dbl, dbl, dbl, i32, i32, vp, vp, dbl, dbl, dbl, dbl, i32,
-                                     vp, vp, vp, vp, vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sosgpu_profile_nogas.restype = i32
+        L.sosgpu_profile_nogas.argtypes = [i32, dbl, dbl, dbl, dbl, vp, vp]
         L.sosgpu_os_flops.restype = i32
         L.sosgpu_os_flops.argtypes = [vp, i32, vp, vp, vp, C.POINTER(dbl)]
         L.sosgpu_last_solve_ms.restype = i32

@@ -1159,7 +1159,7 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
                               int nblev, const double *d_altabs, const double *d_tabs,
                               double a_tronc, double piz, double piztr, double zout, int lp,
                               double *d_prof, int32_t *d_nt, int32_t *d_iborm, double *d_zprof,
-                              int32_t *d_jout, double *d_zz, double *d_scal, void *stream)
+                              int32_t *d_jout, double *d_zz, double *d_scal, const double *d_nogas, void *stream)
 {
     if (!cx || nb < 1 || lp < 2 || !d_prof || !d_nt || !d_iborm || !d_zprof || !d_scal) return SOSGPU_E_ARG;
     if ((d_jout == nullptr) != (d_zz == nullptr)) return SOSGPU_E_ARG;
@@ -1168,27 +1168,46 @@ extern "C" int sosgpu_profile(sosgpu_ctx *cx, int nb, double tr, double hr, doub
     if (!(hr > 0.) || !(ha > 0.) || tr < 0. || ta < 0.) return SOSGPU_E_ARG;
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t st = (hipStream_t)stream;
-    const int NG = 608;
+    const int NG = SOSGPU_NOGAS_LEVELS;
     double t_first = 0., t_layer = 0.;
     const int nt_ng = profile_nogas_grid(tr, ta, &t_first, &t_layer);
     if (nt_ng < 0) return SOSGPU_E_UNSUPPORTED;        // more than CTE_OS_NT levels (IER = -1 in the reference)
     if (lp <= nt_ng) return SOSGPU_E_ARG;
-    // the no-gas profile is made on `stream` in front of the bins' kernel: nothing is waited for, so profiles, solve and aggregate
-    // of a wavelength queue up behind one another without a host stall
-    if (!cx->prof_ng) { if (int rc = dev_alloc(cx, &cx->prof_ng, (size_t)4 * NG)) return rc; }
-    else if (cx->prof_ng_stream != st) HIPCHK(sync_ctx_streams(cx));    // an earlier call on another stream may still be reading it
-    cx->prof_ng_stream = st;
-    launch_profile_nogas(tr, hr, ta, ha, nt_ng, t_first, t_layer, cx->prof_ng, NG, st);
-    HIPCHK(hipGetLastError());
+    // the no-gas profile is made on `stream` in front of the bins' kernel (unless the caller queued it earlier, sosgpu_profile_nogas):
+    // nothing is waited for, so profiles, solve and aggregate of a wavelength queue up behind one another without a host stall
+    const double *ngp = d_nogas;
+    if (!ngp) {
+        if (!cx->prof_ng) { if (int rc = dev_alloc(cx, &cx->prof_ng, (size_t)4 * NG)) return rc; }
+        else if (cx->prof_ng_stream != st) HIPCHK(sync_ctx_streams(cx));    // an earlier call on another stream may still be reading it
+        cx->prof_ng_stream = st;
+        launch_profile_nogas(tr, hr, ta, ha, nt_ng, t_first, t_layer, cx->prof_ng, NG, st);
+        HIPCHK(hipGetLastError());
+        ngp = cx->prof_ng;
+    }
     ProfileArgs a;
     a.nb = nb; a.lp = lp; a.nblev = nblev; a.absprofil = d_tabs ? absprofil : 7; a.smax = cx->d.smax; a.nt_ng = nt_ng;
     a.tr = tr; a.hr = hr; a.ta = ta; a.ha = ha; a.a_tronc = a_tronc; a.piz = piz; a.piztr = piztr; a.zout = zout;
     a.altabs = d_altabs; a.tabs = d_tabs;
-    a.z_ng = cx->prof_ng; a.h_ng = cx->prof_ng + NG; a.pca_ng = cx->prof_ng + 2 * NG; a.pcm_ng = cx->prof_ng + 3 * NG;
+    a.z_ng = ngp; a.h_ng = ngp + NG; a.pca_ng = ngp + 2 * NG; a.pcm_ng = ngp + 3 * NG;
     a.prof = d_prof; a.zprof = d_zprof; a.zz = d_zz; a.scal = d_scal; a.nt = d_nt; a.iborm = d_iborm; a.jout = d_jout;
     launch_profile(a, st);
     HIPCHK(hipGetLastError());
     note_stream(cx, st);
+    return SOSGPU_OK;
+}
+
+extern "C" int sosgpu_profile_nogas(int device, double tr, double hr, double ta, double ha, double *d_nogas, void *stream)
+{
+    if (!d_nogas || !(hr > 0.) || !(ha > 0.) || tr < 0. || ta < 0.) return SOSGPU_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SOSGPU_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SOSGPU_E_ARG;
+    double t_first = 0., t_layer = 0.;
+    const int nt_ng = profile_nogas_grid(tr, ta, &t_first, &t_layer);
+    if (nt_ng < 0) return SOSGPU_E_UNSUPPORTED;
+    HIPCHK(hipSetDevice(device));
+    launch_profile_nogas(tr, hr, ta, ha, nt_ng, t_first, t_layer, d_nogas, SOSGPU_NOGAS_LEVELS, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
     return SOSGPU_OK;
 }
 

@@ -983,6 +983,15 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
         tr = rayleigh_optical_thickness(p["wa_simu"], p["psurf"])
     ha = p["ha"] if ta else 1.0
     zout = float(p["zout"])
+    # head start: the level placement of the wavelength's no-gas profile (a ~1 ms serial chain on one wavefront) is queued now and
+    # runs while the host prepares gas tables, surface and context (a refused profile is reported by make_profiles below)
+    nogas = None
+    if iprofil == 1:
+        try:
+            from .solver import nogas_profile
+            nogas = nogas_profile(tr, p["hr"], ta, ha, device)
+        except Exception:
+            nogas = None
 
     # --- gas absorption: SOS_PREPA_ABSPROFILE + the weights of the CKD bins (SOS_PROC.F:3359-3416)
     use_gas = absprofil != 7
@@ -1073,7 +1082,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
             # of tests/test_profile.py)
             try:
                 bins = ctx.make_profiles(1, tr, p["hr"], ta, ha, None, None, a_tronc=a_tronc, piz=piz, piztr=piztr, zout=zout,
-                                         absprofil=7)
+                                         absprofil=7, nogas=nogas)
             except Exception as e:
                 raise SosProcError("SOS_PROFILE: %s" % e, ier=-1)
             aik = np.ones(1)
@@ -1115,7 +1124,7 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
             try:
                 if len(aik):
                     bins = ctx.make_profiles(len(aik), tr, p["hr"], ta, ha, prep["altabs"], tabs, a_tronc=a_tronc, piz=piz,
-                                             piztr=piztr, zout=zout, absprofil=absprofil)
+                                             piztr=piztr, zout=zout, absprofil=absprofil, nogas=nogas)
                 else:
                     bins = dict(nb=0, scal=None)
             except Exception as e:

@@ -74,6 +74,19 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def nogas_profile(tr, hr, ta, ha, device=0):
+    """Queue the no-gas profile of a wavelength (SOS_PROFIL.F:349-489) on the current stream ahead of make_profiles
+    (sosgpu_profile_nogas): its level placement is a ~1 ms serial chain on one wavefront that only needs the two optical
+    thicknesses and scale heights, so it can run while the host is still preparing the wavelength.  Returns the device block
+    to pass to SosContext.make_profiles(nogas=...)."""
+    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    ng = torch.empty(4 * capi.NOGAS_LEVELS, dtype=torch.float64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    capi.check(capi.lib().sosgpu_profile_nogas(dev.index or 0, float(tr), float(hr), float(ta), float(ha), _ptr(ng), st),
+               "sosgpu_profile_nogas")
+    return ng
+
+
 SEG = None          # run_sos._seg when SOS_PREPARE_SEGMENTS is set (host-time diagnostic), else None
 
 
@@ -216,12 +229,13 @@ class SosContext:
         return tabs
 
     def make_profiles(self, nb, tr, hr, ta, ha, altabs=None, tabs=None, *, a_tronc=0.0, piz=1.0, piztr=1.0, zout=-1.0,
-                      lp=608, absprofil=1):
+                      lp=608, absprofil=1, nogas=None):
         """SOS_PROFILE (IPROFIL=1) + SOS_DISC + the SOS.F rescale for nb CKD bins ON THE DEVICE (sosgpu_profile):
         tabs[nb][nblev] is each bin's cumulative gas absorption optical depth on the descending altitude grid
         altabs[nblev] (None: no gas).  Returns the same dict upload_bins returns (ready for solve()), plus `zprof` and
         the per-bin scalars `scal` [nb][4] = {0, TTOT_TRONC, TTOT_VRAI, TAUOUT} that aggregate() takes.
-        Bins whose profile needs more than CTE_OS_NT levels come back with nt = -1 (the reference's IER = -1)."""
+        Bins whose profile needs more than CTE_OS_NT levels come back with nt = -1 (the reference's IER = -1).
+        nogas: the block nogas_profile(tr, hr, ta, ha) queued earlier on this stream (head start), or None."""
         d = self.device
         t_alt = t_tab = None
         nblev = 0
@@ -245,7 +259,7 @@ class SosContext:
             zz = fb[nb * (4 * lp + 4):]
         capi.check(capi.lib().sosgpu_profile(self._h, nb, tr, hr, ta, ha, int(absprofil), nblev, _ptr(t_alt), _ptr(t_tab),
                                              a_tronc, piz, piztr, zout, lp, _ptr(prof), _ptr(nt), _ptr(iborm),
-                                             _ptr(zprof), _ptr(jout), _ptr(zz), _ptr(scal), self._stream()),
+                                             _ptr(zprof), _ptr(jout), _ptr(zz), _ptr(scal), _ptr(nogas), self._stream()),
                    "sosgpu_profile")
         return dict(nb=nb, lp=lp, perm=None, nt=nt, iborm=iborm, prof=prof, jout=jout, zz=zz, zprof=zprof, scal=scal)
 
