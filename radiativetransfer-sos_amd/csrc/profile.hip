@@ -173,6 +173,38 @@ __device__ double disc_wave(double dt, double ta, double ha, double tr, double h
     return zres;
 }
 
+// The first level below the top of the atmosphere (SOS_PROFIL.F:424-433 without gas, :601-624 with): Z = Z - DELTA_Z from Z0
+// until the optical depth above Z reaches T_FIRST -- ~1700 steps of two exponentials each down to 35 km, the reference's serial
+// scan, and half of the time this file's kernels took.  By the 64 lanes of a wavefront: a block of 64 consecutive steps at a
+// time, lane l forming ITS altitude by the same l + 1 subtractions the serial loop makes (so it is bit for bit the loop's
+// value) and evaluating the optical depth there; the first lane whose depth is not below T_FIRST is where the loop stops.
+template <bool GAS>
+__device__ double scan_first_wave(double tr, double hr, double ta, double ha, const GasProf &g, double t_first, double z0,
+                                  double delta_z)
+{
+    const int lane = threadIdx.x & 63;
+    double zbase = z0;
+    for (int blk = 0; blk < 65536; blk++) {                  // (the serial loop has no guard either: TAU(Z) reaches T_FIRST or Z = -inf)
+        double z = zbase;
+        for (int j = 0; j <= lane; j++) z = z - delta_z;     // lane l: step blk * 64 + l + 1 of the serial loop
+        double dtau;
+        if (GAS) {
+            double vg;
+            const int j = g.seg(z);
+            if (z <= g.alt[0]) {
+                const double zz = (z - g.alt[j - 2]) / (g.alt[j - 1] - g.alt[j - 2]);
+                vg = (1 - zz) * g.tab[j - 2] + zz * g.tab[j - 1];
+            } else vg = 0.;
+            const double vr = tr * exp(-z / hr), va = ta * exp(-z / ha);
+            dtau = vr + va + vg;
+        } else dtau = tr * exp(-z / hr) + ta * exp(-z / ha);
+        const unsigned long long stop = __ballot(!(dtau < t_first));
+        if (stop) return lane_read(z, __builtin_ctzll(stop));
+        zbase = lane_read(z, 63);
+    }
+    return zbase;
+}
+
 }  // namespace
 
 // The no-gas profile of the wavelength (SOS_PROFIL.F:349-489): level altitudes by equal optical-depth steps of molecules +
@@ -197,8 +229,8 @@ __global__ __launch_bounds__(64) void k_profile_nogas(double tr, double hr, doub
     }
     GasProf g;
     g.n = 0; g.alt = nullptr; g.tab = nullptr;                   // (never read: TG_ZLIM = 0 below)
-    double dtau = 0., zz = TOA;
-    while (dtau < t_first) { zz = zz - DELTA_Z; dtau = tr * exp(-zz / hr) + ta * exp(-zz / ha); }
+    double zz = scan_first_wave<false>(tr, hr, ta, ha, g, t_first, TOA, DELTA_Z);
+    const double dtau = tr * exp(-zz / hr) + ta * exp(-zz / ha);
     double vr = tr * exp(-zz / hr), va = ta * exp(-zz / ha);
     double hmol_p = vr, haer_p = va;
     const double z1 = zz;
@@ -300,7 +332,10 @@ __global__ __launch_bounds__(64) void k_profile(ProfileArgs a, int bpw)
             const int i = nt;
             if (i > OS_NT - 1 || i >= a.lp - 1) { bad = true; break; }
             double vr, va, vg;
-            if (i == 1) {
+            if (i == 1 && WAVE) {
+                z = scan_first_wave<true>(tr, hr, ta, ha, g, t_first, z, DELTA_Z);
+                ing = 1;
+            } else if (i == 1) {
                 double dtau = 0.;
                 while (dtau < t_first) {
                     z = z - DELTA_Z;
