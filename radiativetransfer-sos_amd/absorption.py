@@ -18,6 +18,7 @@ the six predefined atmospheres come from data/afgl_atmospheres.npz (scripts/make
 Fortran are widened exactly as the compiler does (`_F`)."""
 import functools
 import os
+import threading
 
 import numpy as np
 
@@ -317,11 +318,52 @@ def _atmosphere(psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil, root, _stamp)
     return user, ro, altabs
 
 
+# ---- gas tables of many wavelengths prepared together (run_sos.sos_spectrum) -----------------------------------------------
+# prefetch_gas_tables runs SOS_PREPA_ABSPROFILE for the wavelengths of a chunk and interpolates the layer tables of ALL of them
+# in one vectorised pass (layer_tables_many); prepa_absprofile / layer_tables calls of this thread with the same arguments
+# then return the prepared objects.  Per thread; dropped by the caller at the end of the chunk.
+_PREFETCH = threading.local()
+
+
+def prefetch_gas_tables(requests):
+    """requests: argument tuples of prepa_absprofile (wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil).  A
+    request that fails is left to the call that owns it."""
+    preps = {}
+    root = None
+    try:
+        root = fic_root()
+    except AbsorptionError:
+        return 0
+    for r in requests:
+        key = tuple(r) + (root,)
+        if key in preps:
+            continue
+        try:
+            preps[key] = prepa_absprofile(*r, root=root)
+        except (AbsorptionError, OSError, ValueError):
+            pass
+    try:
+        layer_tables_many(list(preps.values()))
+    except AbsorptionError:
+        pass                                           # (raised again, by its owner, in layer_tables)
+    _PREFETCH.preps = preps
+    return len(preps)
+
+
+def drop_prefetched_gas_tables():
+    _PREFETCH.preps = None
+
+
 def prepa_absprofile(wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil=None, root=None):
     """SOS_PREPA_ABSPROFILE.  Returns dict(nu, lamb1, altabs[50] descending, userprofil[50][13], ro[8][50] molecules/cm2
     per layer (J = 1 lowest layer; entry 50 keeps the level value, as in the reference), gas tables of the interval
     LAMB1: nexp[8], kdis_ai[5][8], ki[8] (per gas [5][NP][NT] / H2O [5][NC][NP][NT]), tab_pres, tab_temp, tab_conc)."""
     root = root or fic_root()
+    pre = getattr(_PREFETCH, "preps", None)
+    if pre:
+        hit = pre.get((wa, nustep, psurf, h2o, o3, co2, ch4, absprofil, ficabsprofil, root))
+        if hit is not None:
+            return hit
     stamp = None
     if absprofil == 0:
         try:
@@ -554,65 +596,120 @@ def _spline_rows_finite(g, x, y, dy1, dyn):
     return d2
 
 
+def _pairs_values(g, x, a0, a1):
+    """The pressure and temperature interpolations of COEFF_ABS_CKD for a stack of (gas, term) tables already reduced to the two
+    bracketing pressure rows: a0, a1 [pairs][La][NT] -> k of every pair and active layer [pairs][La]."""
+    if g.bad_h:
+        raise AbsorptionError("ERROR for SPLINT interpolation")
+    npair, la = a0.shape[0], g.n
+    xki = (((a1 - a0) / g.pw) * g.pd + a1).reshape(npair * la, -1)
+    dy1 = (xki[:, 1] - xki[:, 0]) / (x[1] - x[0])
+    dyn = (xki[:, -1] - xki[:, -2]) / (x[-1] - x[-2])
+    if np.any(dy1 > _F(.99E30)) or np.any(dyn > _F(.99E30)):
+        d2 = _spline_rows(x, xki, dy1, dyn)
+    else:
+        d2 = _spline_rows_finite(g, x, xki, dy1, dyn)
+    rows = np.arange(npair * la)
+    klo, khi = np.tile(g.klo, npair), np.tile(g.khi, npair)
+    tl = lambda a: np.tile(a, npair)
+    val = tl(g.aa) * xki[rows, klo] + tl(g.bb) * xki[rows, khi] + (tl(g.a3) * d2[rows, klo] + tl(g.b3) * d2[rows, khi]) * tl(g.h2) / 6.
+    neg = val < 0.
+    if neg.any():
+        it = tl(g.it)
+        lin = ((xki[rows, it + 1] - xki[rows, it]) / tl(g.lw)) * tl(g.ld) + xki[rows, it + 1]
+        val = np.where(neg, lin, val)
+        if np.any(val < 0.):
+            raise AbsorptionError("COEFF_ABS_CKD : ERROR_923 : Calculations give ki < 0 : uncorrect value!")
+    return val.reshape(npair, la)
+
+
+def _geometry_of(prep):
+    return _layer_geometry(np.ascontiguousarray(prep["userprofil"]).tobytes(), np.ascontiguousarray(prep["tab_pres"]).tobytes(),
+                           np.ascontiguousarray(prep["tab_temp"]).tobytes(), np.ascontiguousarray(prep["tab_conc"]).tobytes())
+
+
+def _absorbing_pairs(prep):
+    """(gas, term) pairs of the interval whose table is not all zero (NMAXAI = 0: the gas does not absorb here, every
+    interpolation of zeros is zero), in the reference's loop order (term outermost)."""
+    out = []
+    for term in range(CKD_NAI_MAX):
+        for k in range(NBABS):
+            if term < prep["nexp"][k] and prep["ki"][k][term].any():
+                out.append((k, term))
+    return out
+
+
 def layer_tables(prep):
     """XK(gas, term, layer) RO(gas, layer) of SOS_ABSPROFILE.F:325-353 for every exponential term of every gas:
     returns (xk [8][5][49], ro [8][49]) with layer index J-1, J = 1 the TOP layer (the reference's loop order).
     The 49 layers of ALL (term, gas) pairs with a non-zero table are interpolated together, on brackets and weights kept per
     atmosphere (_layer_geometry: a spectrum shares one atmosphere); element by element the arithmetic of coeff_abs_ckd --
-    tests/test_absorption.py holds it against the pair-by-pair and the layer-by-layer forms, bit for bit."""
-    u = prep["userprofil"]
+    tests/test_absorption.py holds it against the pair-by-pair and the layer-by-layer forms, bit for bit.  A prep that went
+    through layer_tables_many carries its tables already."""
+    done = prep.get("_layer_tables")
+    if done is not None:
+        return done
     nl = NLEVEL
     xk = np.zeros((NBABS, CKD_NAI_MAX, nl - 1))
     j = np.arange(1, nl)
     ro = prep["ro"][:, nl - j - 1].copy()             # RO(K, NLEVEL-J)
-    x = prep["tab_temp"]
-    g = _layer_geometry(np.ascontiguousarray(u).tobytes(), np.ascontiguousarray(prep["tab_pres"]).tobytes(),
-                        np.ascontiguousarray(x).tobytes(), np.ascontiguousarray(prep["tab_conc"]).tobytes())
-    if g.n:
-        pairs, a0s, a1s = [], [], []
-        for term in range(CKD_NAI_MAX):
-            for k in range(NBABS):
-                if term >= prep["nexp"][k]:
-                    continue
-                ki = prep["ki"][k][term]
-                if not ki.any():                       # NMAXAI = 0: the gas does not absorb here, every interpolation of zeros is zero
-                    continue
-                if k == 0:                             # water vapour: first along the concentration axis
-                    k0, k1 = ki[g.ic], ki[g.ic + 1]                            # [La][NP][NT]
-                    xkh = ((k1 - k0) / (g.c1 - g.c0)) * g.cd + k1
-                    a0, a1 = xkh[g.rows, g.ip], xkh[g.rows, g.ip + 1]
-                else:
-                    a0, a1 = ki[g.ip], ki[g.ip + 1]                            # [La][NT]
-                pairs.append((k, term))
-                a0s.append(a0)
-                a1s.append(a1)
-        if pairs:
-            if g.bad_h:
-                raise AbsorptionError("ERROR for SPLINT interpolation")
-            npair, la = len(pairs), g.n
-            a0, a1 = np.stack(a0s), np.stack(a1s)                              # [pairs][La][NT]
-            xki = (((a1 - a0) / g.pw) * g.pd + a1).reshape(npair * la, -1)
-            dy1 = (xki[:, 1] - xki[:, 0]) / (x[1] - x[0])
-            dyn = (xki[:, -1] - xki[:, -2]) / (x[-1] - x[-2])
-            if np.any(dy1 > _F(.99E30)) or np.any(dyn > _F(.99E30)):
-                d2 = _spline_rows(x, xki, dy1, dyn)
+    g = _geometry_of(prep)
+    pairs = _absorbing_pairs(prep) if g.n else []
+    if pairs:
+        a0s, a1s = [], []
+        for k, term in pairs:
+            ki = prep["ki"][k][term]
+            if k == 0:                                 # water vapour: first along the concentration axis
+                k0, k1 = ki[g.ic], ki[g.ic + 1]                                # [La][NP][NT]
+                xkh = ((k1 - k0) / (g.c1 - g.c0)) * g.cd + k1
+                a0, a1 = xkh[g.rows, g.ip], xkh[g.rows, g.ip + 1]
             else:
-                d2 = _spline_rows_finite(g, x, xki, dy1, dyn)
-            rows = np.arange(npair * la)
-            klo, khi = np.tile(g.klo, npair), np.tile(g.khi, npair)
-            tl = lambda a: np.tile(a, npair)
-            val = tl(g.aa) * xki[rows, klo] + tl(g.bb) * xki[rows, khi] + (tl(g.a3) * d2[rows, klo] + tl(g.b3) * d2[rows, khi]) * tl(g.h2) / 6.
-            neg = val < 0.
-            if neg.any():
-                it = tl(g.it)
-                lin = ((xki[rows, it + 1] - xki[rows, it]) / tl(g.lw)) * tl(g.ld) + xki[rows, it + 1]
-                val = np.where(neg, lin, val)
-                if np.any(val < 0.):
-                    raise AbsorptionError("COEFF_ABS_CKD : ERROR_923 : Calculations give ki < 0 : uncorrect value!")
-            val = val.reshape(npair, la)
-            for q, (k, term) in enumerate(pairs):
-                xk[k, term][g.act] = val[q]
+                a0, a1 = ki[g.ip], ki[g.ip + 1]                                # [La][NT]
+            a0s.append(a0)
+            a1s.append(a1)
+        val = _pairs_values(g, prep["tab_temp"], np.stack(a0s), np.stack(a1s))
+        for q, (k, term) in enumerate(pairs):
+            xk[k, term][g.act] = val[q]
     return xk, ro
+
+
+def layer_tables_many(preps):
+    """layer_tables for the wavelengths of a spectrum in one pass: the (gas, term) pairs of ALL intervals that share an
+    atmosphere and table axes go through the interpolations together (the same element-wise statements on longer arrays:
+    bit-identical to the one-by-one form).  Attaches the tables to every prep (layer_tables then returns them)."""
+    nl = NLEVEL
+    j = np.arange(1, nl)
+    groups = {}
+    for prep in preps:
+        if prep.get("_layer_tables") is not None:
+            continue
+        g = _geometry_of(prep)
+        groups.setdefault(id(g), (g, []))[1].append(prep)
+    for g, members in groups.values():
+        outs = [np.zeros((NBABS, CKD_NAI_MAX, nl - 1)) for _ in members]
+        if g.n:
+            where, dry, wet = [], [], []                 # (member, gas, term) of every pair; tables of the dry gases / of H2O
+            for m, prep in enumerate(members):
+                for k, term in _absorbing_pairs(prep):
+                    (wet if k == 0 else dry).append((m, k, term))
+            a0s, a1s = [], []
+            x = members[0]["tab_temp"]
+            if dry:
+                kis = np.stack([members[m]["ki"][k][term] for m, k, term in dry])          # [P][NP][NT]
+                a0s.append(kis[:, g.ip]); a1s.append(kis[:, g.ip + 1])                      # [P][La][NT]
+                where += dry
+            if wet:
+                kis = np.stack([members[m]["ki"][k][term] for m, k, term in wet])          # [P][NC][NP][NT]
+                k0, k1 = kis[:, g.ic], kis[:, g.ic + 1]                                    # [P][La][NP][NT]
+                xkh = ((k1 - k0) / (g.c1 - g.c0)) * g.cd + k1
+                a0s.append(xkh[:, g.rows, g.ip]); a1s.append(xkh[:, g.rows, g.ip + 1])
+                where += wet
+            if where:
+                val = _pairs_values(g, x, np.concatenate(a0s), np.concatenate(a1s))
+                for q, (m, k, term) in enumerate(where):
+                    outs[m][k, term][g.act] = val[q]
+        for prep, xk in zip(members, outs):
+            prep["_layer_tables"] = (xk, prep["ro"][:, nl - j - 1].copy())
 
 
 def layer_tables_scalar(prep):

@@ -828,6 +828,21 @@ def _aerosols_at_waref(p, nb_mie, os_nb, device):
     return out
 
 
+def _gas_table_request(kw):
+    """The arguments of the SOS_PREPA_ABSPROFILE call _prepare(kw) will make (absorption.prefetch_gas_tables), or None when the
+    call has no gas absorption or its parameters are refused (the real pass reports)."""
+    try:
+        p = dict(kw)
+        validate_parameters(p)
+        absprofil = int(p["absprofil"])
+        if absprofil == _I or not 0 <= absprofil <= 6 or p["nustep"] == _I or p["wa_simu"] == _D:
+            return None
+        return (p["wa_simu"], float(p["nustep"]), p["psurf"], p["h2o"], p["o3"], p["co2"], p["ch4"], absprofil,
+                str(p["ficabsprofil"]).strip())
+    except Exception:
+        return None
+
+
 def _size_integral_requests(kw, aer_phase, device):
     """The size integrals the aerosol step of _prepare(kw, aer_phase) will ask for at the simulation wavelength (keys of
     aerosols.prefetch_size_integrals); empty when the step does not run or its parameters are refused (the real pass reports)."""
@@ -1359,6 +1374,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     from .solver import ContextTable, SosBinError, _upload, concat_bins, solve_spectrum
     from . import dist as _dist
     from . import aerosols as _aer
+    from . import absorption as _abs
     capi.lib()
     nwl = len(kwargs_list)
     if aer_phases is None:
@@ -1403,6 +1419,10 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 if reqs:
                     with torch.cuda.stream(aer_st):
                         _aer.prefetch_size_integrals(reqs)
+                # ... and the gas tables of the chunk's wavelengths, interpolated to the layers in one pass
+                greqs = [r for r in (_gas_table_request(kwargs_list[i]) for i in idx) if r is not None]
+                if greqs:
+                    _abs.prefetch_gas_tables(greqs)
                 for k, i in enumerate(idx):
                     with torch.cuda.stream(side[k % len(side)]):
                         pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
@@ -1478,6 +1498,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 tm["finish"] += time.perf_counter() - t4
             finally:
                 _aer.drop_prefetched_size_integrals()
+                _abs.drop_prefetched_gas_tables()
                 for st in side + [aer_st]:
                     st.synchronize()
                 main_st.synchronize()                             # the table launches read every context's operators

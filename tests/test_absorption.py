@@ -191,3 +191,17 @@ def test_vectorised_layer_tables_equal_the_scalar_restatement(pkg, fic):
         assert np.array_equal(xv, xs) and np.array_equal(rv, rs_) and (xs != 0).sum() > 100
         xp, rp = A.layer_tables_by_pair(prep)
         assert np.array_equal(xp, xs) and np.array_equal(rp, rs_)
+    # the wavelengths of a spectrum in one pass (sos_spectrum): the same tables, bit for bit, and served through the prefetch
+    reqs = [(0.762, 10.0, 1013.0, -999., -999., -999., -999., 2, None), (1.0e4 / 15925.0, 10.0, 1013.0, 2.5, -999., -999., -999., 1, None),
+            (1.0e4 / 15925.0, 10.0, 1013.0, -999., -999., -999., -999., 6, None), (0.7625, 10.0, 1013.0, -999., -999., -999., -999., 2, None)]
+    one = [A.layer_tables(A.prepa_absprofile(*r)) for r in reqs]
+    try:
+        assert A.prefetch_gas_tables(reqs + reqs[:1]) == len(reqs)
+        for r, (x1, r1) in zip(reqs, one):
+            prep = A.prepa_absprofile(*r)
+            assert "_layer_tables" in prep
+            xm, rm = A.layer_tables(prep)
+            assert np.array_equal(xm, x1) and np.array_equal(rm, r1)
+    finally:
+        A.drop_prefetched_gas_tables()
+    assert "_layer_tables" not in A.prepa_absprofile(*reqs[0])
