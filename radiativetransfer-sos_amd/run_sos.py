@@ -1339,7 +1339,7 @@ def spectrum_costs(kwargs_list):
     return costs
 
 
-def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None, prep_streams=16):
+def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256, timings=None, prep_streams=16, parts=4):
     """A spectrum of sos_proc calls -- one per wavelength, as the reference issues them one after the other
     (binding/run_sos.py:640-695; the bin loop of each is SOS_PROC.F:3459-3594) -- as ONE pass over the GPU:
 
@@ -1364,6 +1364,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     call (-SOS_Main.ResRoot) are written by the rank that owns it.
     aer_phases: optional list parallel to kwargs_list of `aer_phase` dictionaries (see sos_proc) or None.
     timings: optional dict, filled with host-side phase times in seconds (prepare, solve_launch, wait, trphi, finish).
+    parts: a chunk is handed to the solver in this many parts (the solves of one part overlap the host preparation of the next).
     prep_streams: HIP streams the per-wavelength preparation kernels are spread over (export GPU_MAX_HW_QUEUES=16 to give them
     hardware queues of their own, solver.solve_many).  The preparation kernels of one wavelength are a serial chain of about
     3 ms on a few wavefronts (level placement of the no-gas profile and of every bin: bisections), so the device side alone
@@ -1423,50 +1424,58 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 greqs = [r for r in (_gas_table_request(kwargs_list[i]) for i in idx) if r is not None]
                 if greqs:
                     _abs.prefetch_gas_tables(greqs)
-                for k, i in enumerate(idx):
-                    with torch.cuda.stream(side[k % len(side)]):
-                        pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
-                    if debug:
-                        torch.cuda.synchronize(dev)
-                        print("[sos_spectrum] prepared", i, flush=True)
-                    pl.writes_files = True
-                    pl.index = i
-                    plans.append(pl)
-                for st in side:
-                    main_st.wait_stream(st)
-                t1 = time.perf_counter()
-                tm["prepare"] += t1 - t0
-                # --- groups of wavelengths one launch can cover
-                groups = collections.OrderedDict()
-                single = []
-                for pl in plans:
-                    b = pl.bins
-                    if pl.tdifmug is not None or b["nb"] == 0 or not isinstance(b.get("scal"), torch.Tensor):
-                        single.append(pl)
-                        continue
-                    key = (pl.n, pl.ctx.smax, pl.ctx.os_nb, bool(pl.ctx._rsurf is not None), b["lp"], b["jout"] is not None)
-                    groups.setdefault(key, []).append(pl)
+                # The chunk goes to the solver in a few parts: the solves of a part run on the device while the host prepares the
+                # next one, so that only the last part's solve is waited for below.
                 solved = []                       # (plans, rec [nw][S][3][W], scal [nw][10+N]) device tensors
-                for key, gp in groups.items():
-                    if len(gp) == 1:
-                        single.append(gp[0])
-                        continue
-                    table = ContextTable([pl.ctx for pl in gp])
-                    bins, cob, seg = concat_bins([pl.bins for pl in gp])
-                    aik = _upload(torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])), dev)
-                    if debug:
-                        print("[sos_spectrum] group", key, "wavelengths", [pl.index for pl in gp], "bins", bins["nb"], flush=True)
-                    rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)
-                    if debug:
-                        torch.cuda.synchronize(dev)
-                        print("[sos_spectrum]   done", flush=True)
-                    solved.append((gp, rec, scal, table))
-                for pl in single:
-                    out = pl.ctx.solve(pl.bins, pl.ctx.alloc_outputs(pl.bins["nb"], zero=False))
-                    rec, scal = pl.ctx.aggregate(out, pl.aik, scal=pl.bins.get("scal"), tdifmug=pl.tdifmug)
-                    solved.append(([pl], rec, scal, None))
+                nsub = max(1, int(parts))
+                step = max(1, -(-len(idx) // nsub))
+                for s0 in range(0, len(idx), step):
+                    part = []
+                    for k, i in enumerate(idx[s0:s0 + step], s0):
+                        with torch.cuda.stream(side[k % len(side)]):
+                            pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
+                        if debug:
+                            torch.cuda.synchronize(dev)
+                            print("[sos_spectrum] prepared", i, flush=True)
+                        pl.writes_files = True
+                        pl.index = i
+                        plans.append(pl)
+                        part.append(pl)
+                    for st in side:
+                        main_st.wait_stream(st)
+                    t1 = time.perf_counter()
+                    tm["prepare"] += t1 - t0
+                    # --- groups of wavelengths one launch can cover
+                    groups = collections.OrderedDict()
+                    single = []
+                    for pl in part:
+                        b = pl.bins
+                        if pl.tdifmug is not None or b["nb"] == 0 or not isinstance(b.get("scal"), torch.Tensor):
+                            single.append(pl)
+                            continue
+                        key = (pl.n, pl.ctx.smax, pl.ctx.os_nb, bool(pl.ctx._rsurf is not None), b["lp"], b["jout"] is not None)
+                        groups.setdefault(key, []).append(pl)
+                    for key, gp in groups.items():
+                        if len(gp) == 1:
+                            single.append(gp[0])
+                            continue
+                        table = ContextTable([pl.ctx for pl in gp])
+                        bins, cob, seg = concat_bins([pl.bins for pl in gp])
+                        aik = _upload(torch.from_numpy(np.concatenate([np.asarray(pl.aik, dtype=np.float64) for pl in gp])), dev)
+                        if debug:
+                            print("[sos_spectrum] group", key, "wavelengths", [pl.index for pl in gp], "bins", bins["nb"], flush=True)
+                        rec, scal = solve_spectrum(table, bins, cob, seg, aik, order=None)
+                        if debug:
+                            torch.cuda.synchronize(dev)
+                            print("[sos_spectrum]   done", flush=True)
+                        solved.append((gp, rec, scal, table))
+                    for pl in single:
+                        out = pl.ctx.solve(pl.bins, pl.ctx.alloc_outputs(pl.bins["nb"], zero=False))
+                        rec, scal = pl.ctx.aggregate(out, pl.aik, scal=pl.bins.get("scal"), tdifmug=pl.tdifmug)
+                        solved.append(([pl], rec, scal, None))
+                    t0 = time.perf_counter()
+                    tm["solve_launch"] += t0 - t1
                 t2 = time.perf_counter()
-                tm["solve_launch"] += t2 - t1
                 # --- one copy of all band scalars (waits for the solves), then every azimuth recomposition back to back
                 scal_all = torch.cat([s.reshape(-1) for _, _, s, _ in solved]).cpu().numpy()
                 t3 = time.perf_counter()
