@@ -85,6 +85,28 @@ def test_device_profile_vs_golden(gpu_pkg, oracle, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gas_weak", "gas_ray", "nogas"])
+def test_nogas_profile_queued_ahead_gives_the_same_bins(gpu_pkg, name):
+    """sosgpu_profile_nogas (the head start run_sos._prepare takes before it has the gas tables) + sosgpu_profile(d_nogas) ==
+    sosgpu_profile making the no-gas profile itself: the same kernel, the same values -- every output bit for bit."""
+    import torch
+    c = cases.profile_case(name)
+    cx = _ctx(gpu_pkg)
+    nb = 3
+    tabs = None if c["tabs"] is None else np.tile(c["tabs"], (nb, 1)) * np.array([[0.2], [1.0], [3.0]])
+    alt = None if tabs is None else c["altabs"]
+    kw = dict(a_tronc=0.3, piz=0.96, piztr=0.94, zout=2.5)
+    a = cx.make_profiles(nb, c["tr"], c["hr"], c["ta"], c["ha"], alt, tabs, absprofil=7 if tabs is None else 1, **kw)
+    ng = gpu_pkg.solver.nogas_profile(c["tr"], c["hr"], c["ta"], c["ha"])
+    b = cx.make_profiles(nb, c["tr"], c["hr"], c["ta"], c["ha"], alt, tabs, absprofil=7 if tabs is None else 1, nogas=ng, **kw)
+    torch.cuda.synchronize()
+    for k in ("nt", "iborm", "prof", "zprof", "scal", "jout", "zz"):
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["nt"].min()) > 50
+    cx.close()
+
+
+@pytest.mark.gpu
 def test_device_profile_rescale_zout_and_solve(gpu_pkg, oracle):
     """Truncation rescale + IBORM + output level on the device == host restatement of SOS.F:521-589 applied to the
     oracle profile; and the device-made bins run through the solver like uploaded ones (bit-identical records)."""
