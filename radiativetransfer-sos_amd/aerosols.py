@@ -361,6 +361,70 @@ def decompo_legendre(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
                 coef_tronca=float(coef), itronc=itronc)
 
 
+def decompo_legendre_many(itronc, xmu, xhr, os_nb, p11_in, p12, p22, p33):
+    """decompo_legendre for B phase functions at once (p11_in, p12, p22, p33: [B][2N+1]; the wavelengths of a chunk of a spectrum):
+    the same statements with a leading batch axis -- sums along the angle axis stay sequential, the scalar expressions of the
+    truncation (log10, acos, 10 ** x of libm) are formed per phase function exactly as the single form forms them -- so every
+    output equals decompo_legendre's bit for bit (tests/test_aerosols.py).  Returns a list of B dictionaries."""
+    p11_in, p12, p22, p33 = (np.asarray(a, dtype=np.float64) for a in (p11_in, p12, p22, p33))
+    nbatch, w = p11_in.shape
+    n = (w - 1) // 2
+    J = lambda j: j + n
+    kk = np.arange(os_nb + 1)
+    sel, xr, pl, pol, coefs = _legendre_tables(np.ascontiguousarray(xmu, dtype=np.float64).tobytes(), os_nb)
+    ttt = p11_in
+    p11 = ttt.copy()
+    itr = np.full(nbatch, 1 if itronc else 0)
+    if itronc:
+        k1 = next((j - 1 for j in range(1, n + 1) if xmu[J(j)] > MU1_TRONCA), None)
+        k2 = next((j - 1 for j in range(1, n + 1) if xmu[J(j)] > MU2_TRONCA), None)
+        if k1 is None or k2 is None:
+            raise AerosolError("truncation angles outside the Mie angle set")
+        ac1, ac2 = math.acos(xmu[J(k1)]), math.acos(xmu[J(k2)])
+        acj = [math.acos(xmu[J(j)]) for j in range(k2 + 1, n + 1)]
+        for b in range(nbatch):
+            x1 = math.log10(p11[b, J(k2)])
+            aa = (x1 - math.log10(p11[b, J(k1)])) / (ac2 - ac1)
+            for q, j in enumerate(range(k2 + 1, n + 1)):
+                p11[b, J(j)] = 10 ** (x1 + aa * (acj[q] - ac2))
+    wgt = pl[:os_nb + 1][None, :, :]
+    beta11 = np.cumsum((p11[:, sel] * xhr[sel])[:, None, :] * wgt, axis=-1)[..., -1]
+    beta11 = (2 * kk + 1) * beta11 * .5
+    coef = 2 * (1 - beta11[:, 0]) if itronc else np.zeros(nbatch)
+    if itronc:
+        redo = coef < SEUIL_TRONCA                      # truncation too small to matter: again without it (SOS_AEROSOLS.F:4195-4214)
+        if redo.any():
+            p11[redo] = ttt[redo]
+            b11 = np.cumsum((p11[redo][:, sel] * xhr[sel])[:, None, :] * wgt, axis=-1)[..., -1]
+            beta11[redo] = (2 * kk + 1) * b11 * .5
+            coef = np.where(redo, 0.0, coef)
+            itr[redo] = 0
+    ps, ts = p11[:, sel], ttt[:, sel]
+    xxx = xhr[sel] * p12[:, sel] * ps / ts
+    xb = xhr[sel] * p22[:, sel] * (ps / ts)
+    xx = xhr[sel] * p33[:, sel] * ps / ts
+    gamma12 = np.zeros((nbatch, os_nb + 1))
+    gamma12[:, 2:] = np.cumsum(xxx[:, None, :] * pol[2:os_nb + 1][None], axis=-1)[..., -1]
+    beta22 = np.cumsum(xb[:, None, :] * wgt, axis=-1)[..., -1]
+    delta33 = np.cumsum(xx[:, None, :] * wgt, axis=-1)[..., -1]
+    beta22 = beta22 * (2. * kk + 1.) * .5
+    delta33 = delta33 * (2. * kk + 1.) * .5
+    gamma12 = gamma12 * (2. * kk + 1.) * .5
+    co1, co2r, xn, jn_idx, xm, jm_idx = coefs
+    last = lambda a: np.cumsum(a, axis=-1)[..., -1]
+    s1, s2 = last(xn * beta22[:, jn_idx]), last(xn * delta33[:, jn_idx])
+    s3, s4 = last(xm * beta22[:, jm_idx]), last(xm * delta33[:, jm_idx])
+    alp, zeta = np.zeros((nbatch, os_nb + 1)), np.zeros((nbatch, os_nb + 1))
+    co3 = co2r * delta33[:, 2:]
+    co2 = co2r * beta22[:, 2:]
+    zeta[:, 2:] = co3 - co1 * (s2 - s3)
+    alp[:, 2:] = co2 - co1 * (s1 - s4)
+    z1 = beta11[:, :1]
+    alp, bet, gam, zet, b22, d33 = alp / z1, beta11 / z1, gamma12 / z1, zeta / z1, beta22 / z1, delta33 / z1
+    return [dict(alpha=alp[b], beta=bet[b], gamma=gam[b], zeta=zet[b], beta22=b22[b], delta33=d33[b], coef_tronca=float(coef[b]),
+                 itronc=int(itr[b])) for b in range(nbatch)]
+
+
 def _rmax_lnd(rmodal, var):
     return rmodal * math.exp(var * var) * math.exp(var * math.sqrt(-2. * math.log(COEF_NRMAX)))
 
@@ -731,7 +795,13 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
         return None
     if p22 is None:
         p22 = p11.copy()                                # spherical particles (:1234, :1495, :1688, :2118, :2762)
-    d = decompo_legendre(itronc, xmu, xhr, os_nb, p11, p12, p22, p33)
+    if getattr(_TLS, "defer_expansion", False):         # aerosols_many: the expansions of a chunk of wavelengths are formed together
+        return ("expansion", itronc, xmu, xhr, os_nb, p11, p12, p22, p33, kmat1, kmat2)
+    return _aerosols_file(decompo_legendre(itronc, xmu, xhr, os_nb, p11, p12, p22, p33), kmat1, kmat2)
+
+
+def _aerosols_file(d, kmat1, kmat2):
+    """The content of Aerosols.txt from the expansion d and the cross sections (the tail of SOS_AEROSOLS)."""
     piz = kmat2 / kmat1
     ct = d["coef_tronca"]
     piztr = piz * (1. - ct / 2.) / (1. - piz * ct / 2.)
@@ -740,3 +810,38 @@ def aerosols(p, wa, ta, nb_gauss_mie, os_nb, *, at_waref=False, device=0):
     a_f, piztr_f = float("%9.5f" % ct), float("%9.5f" % piztr)
     return dict(alpha=q[0], beta=q[1], gamma=q[2], zeta=q[3], a_tronc=a_f, piztr=piztr_f,
                 piz=piztr_f / (1 + 0.5 * a_f * (piztr_f - 1)), kmat1=kmat1, kmat2=kmat2, coef_tronca=ct)
+
+
+def aerosols_many(calls, nb_gauss_mie, os_nb, device=0):
+    """aerosols(p, wa, ta, ...) for a list of (p, wa, ta) -- the wavelengths of a chunk of a spectrum -- with the Legendre
+    expansions of all of them formed in one vectorised pass (decompo_legendre_many).  Returns a list parallel to `calls`; an
+    entry is None when its call raised (the caller repeats it on its own and reports).  Outputs equal aerosols()'s bit for bit."""
+    out = [None] * len(calls)
+    todo = collections.OrderedDict()
+    _TLS.defer_expansion = True
+    try:
+        for i, (p, wa, ta) in enumerate(calls):
+            try:
+                r = aerosols(p, wa, ta, nb_gauss_mie, os_nb, at_waref=False, device=device)
+            except Exception:
+                continue
+            if isinstance(r, tuple):
+                _, itronc, xmu, xhr, nb, p11, p12, p22, p33, k1, k2 = r
+                todo.setdefault((itronc, xmu.tobytes(), xhr.tobytes(), nb), []).append((i, xmu, xhr, p11, p12, p22, p33, k1, k2))
+            else:
+                out[i] = r
+    finally:
+        _TLS.defer_expansion = False
+    for (itronc, _, _, nb), members in todo.items():
+        try:
+            ds = decompo_legendre_many(itronc, members[0][1], members[0][2], nb, np.stack([m[3] for m in members]),
+                                       np.stack([m[4] for m in members]), np.stack([m[5] for m in members]),
+                                       np.stack([m[6] for m in members]))
+        except Exception:
+            continue
+        for m, d in zip(members, ds):
+            try:
+                out[m[0]] = _aerosols_file(d, m[7], m[8])
+            except Exception:
+                pass
+    return out

@@ -843,18 +843,27 @@ def _gas_table_request(kw):
         return None
 
 
-def _size_integral_requests(kw, aer_phase, device):
-    """The size integrals the aerosol step of _prepare(kw, aer_phase) will ask for at the simulation wavelength (keys of
-    aerosols.prefetch_size_integrals); empty when the step does not run or its parameters are refused (the real pass reports)."""
-    from . import aerosols as _aer
+def _aerosol_call(kw, aer_phase):
+    """(p, nb_mie, os_nb) of the SOS_AEROSOLS run _prepare(kw, aer_phase) will make at the simulation wavelength, or None when
+    that step does not run or its parameters are refused (the real pass reports)."""
     try:
         p = dict(kw)
         validate_parameters(p)
         if (p["aot_ref"] in (0.0, _D) or aer_phase is not None or str(p["ficuser_aer"]).strip() != "NO_USER_AEROSOLS"
-                or p["waref_aot"] == _D or p["wa_simu"] in (_D, p["waref_aot"])):
-            return []
+                or p["waref_aot"] == _D or p["wa_simu"] in (_D, p["waref_aot"]) or p["imod_aer"] not in (0, 1, 2, 3, 4, 5)):
+            return None
         nb_mie = CTE_DEFAULT_NBMU_MIE if p["nbmu_gauss_mie"] == _I else int(p["nbmu_gauss_mie"])
         os_nb = CTE_DEFAULT_OS_NB if p["nbmu_gauss_mie"] == _I else 2 * nb_mie
+        return p, nb_mie, os_nb
+    except Exception:
+        return None
+
+
+def _size_integral_requests(call, device):
+    """The size integrals the aerosol run `call` (_aerosol_call) will ask for (keys of aerosols.prefetch_size_integrals)."""
+    from . import aerosols as _aer
+    try:
+        p, nb_mie, os_nb = call
         with _aer.collect_size_integrals() as reqs:
             _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device)
         return reqs
@@ -884,14 +893,15 @@ if PREPARE_SEGMENTS is not None:
     _solver_mod.SEG = _seg
 
 
-def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
+def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None, aer_at_wa=None):
     """Everything of one SOS_PROC call up to the CKD bin loop (SOS_PROC.F:1310-3458): parameter checks, SOS_ANGLES,
     SOS_AEROSOLS, SOS_SURFACE, SOS_PREPA_ABSPROFILE, SOS_PREPA_OS, and the profiles of every bin of the band on the device
     (SOS_ABSPROFILE + SOS_PROFILE + the rescale of SOS).  Returns a _Plan whose `ctx` the caller closes.
     shard_bins: with torch.distributed initialised, keep only this rank's slice of the band's bins (sos_proc); False: the
     whole band stays on this rank (sos_spectrum distributes wavelengths, not bins).
     aer_stream: HIP stream (torch.cuda.Stream) for the aerosol step, whose device calls are host-synchronous -- sos_spectrum keeps
-    them off the streams its asynchronous work is queued on."""
+    them off the streams its asynchronous work is queued on.
+    aer_at_wa: the result of SOS_AEROSOLS at the simulation wavelength when sos_spectrum has formed it already (aerosols_many)."""
     _seg(None)
     missing = [k for k in SOS_PROC_KWARGS if k not in kw]
     if missing:
@@ -966,7 +976,8 @@ def _prepare(kw, aer_phase=None, device=0, shard_bins=True, aer_stream=None):
                 ta_model = float(p["aot_ref"])
                 if p["wa_simu"] != p["waref_aot"]:
                     k_ref = aer_phase["kmat1"]
-                    aer_phase = _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device)
+                    aer_phase = (aer_at_wa if aer_at_wa is not None else
+                                 _aer.aerosols(p, p["wa_simu"], 0.1, nb_mie, os_nb, at_waref=False, device=device))
                     ta_model = (aer_phase["kmat1"] / k_ref) * p["aot_ref"]
         except _aer.AerosolError as e:
             raise SosProcError(str(e), ier=-1)
@@ -1414,9 +1425,10 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 for st in side + [aer_st]:
                     st.wait_stream(main_st)
                 # the size-distribution integrals of the chunk's wavelengths, queued ahead (aerosols.prefetch_size_integrals)
+                acalls = {i: c for i, c in ((i, _aerosol_call(kwargs_list[i], aer_phases[i])) for i in idx) if c is not None}
                 reqs = []
-                for i in idx:
-                    reqs += _size_integral_requests(kwargs_list[i], aer_phases[i], device)
+                for c in acalls.values():
+                    reqs += _size_integral_requests(c, device)
                 if reqs:
                     with torch.cuda.stream(aer_st):
                         _aer.prefetch_size_integrals(reqs)
@@ -1424,6 +1436,18 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 greqs = [r for r in (_gas_table_request(kwargs_list[i]) for i in idx) if r is not None]
                 if greqs:
                     _abs.prefetch_gas_tables(greqs)
+                # ... and SOS_AEROSOLS at the simulation wavelength of each, the Legendre expansions formed together (the gas tables
+                # above were made while the size integrals ran)
+                aer_wa = {}
+                by_angles = collections.OrderedDict()
+                for i, (pp, nbm, nbo) in acalls.items():
+                    by_angles.setdefault((nbm, nbo), []).append((i, pp))
+                for (nbm, nbo), members in by_angles.items():
+                    with torch.cuda.stream(aer_st):
+                        res = _aer.aerosols_many([(pp, pp["wa_simu"], 0.1) for _, pp in members], nbm, nbo, device=device)
+                    for (i, _), r in zip(members, res):
+                        if r is not None:
+                            aer_wa[i] = r
                 # The chunk goes to the solver in a few parts: the solves of a part run on the device while the host prepares the
                 # next one, so that only the last part's solve is waited for below.
                 solved = []                       # (plans, rec [nw][S][3][W], scal [nw][10+N]) device tensors
@@ -1433,7 +1457,8 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                     part = []
                     for k, i in enumerate(idx[s0:s0 + step], s0):
                         with torch.cuda.stream(side[k % len(side)]):
-                            pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st)
+                            pl = _prepare(kwargs_list[i], aer_phases[i], device, shard_bins=False, aer_stream=aer_st,
+                                          aer_at_wa=aer_wa.get(i))
                         if debug:
                             torch.cuda.synchronize(dev)
                             print("[sos_spectrum] prepared", i, flush=True)

@@ -276,3 +276,30 @@ def test_vectorised_decompo_equals_the_loop_restatement(pkg):
         for k in ("alpha", "beta", "gamma", "zeta", "beta22", "delta33"):
             assert np.array_equal(a[k], b[k]), (nbm, itr, k)
         assert a["coef_tronca"] == b["coef_tronca"] and a["itronc"] == b["itronc"]
+
+
+def test_batched_decompo_equals_the_single_form(pkg):
+    """decompo_legendre_many (the Legendre expansions of a chunk of wavelengths in one pass, sos_spectrum) == decompo_legendre
+    per phase function, bit for bit: truncated, truncation refused (the retry without it), no truncation asked."""
+    A = pkg.aerosols
+    rng = np.random.default_rng(1)
+    for nbm, osnb in ((12, 24), (16, 32), (40, 80)):
+        xmu, xhr = A.mie_angles(nbm)
+        w = len(xmu)
+        th = np.arccos(np.clip(xmu, -1, 1))
+        rows = []
+        for b in range(9):
+            g = rng.uniform(0.0, 0.9) if b else 0.0                  # b = 0: isotropic -> the truncation is refused
+            hg = (1 - g * g) / (1 + g * g - 2 * g * xmu) ** 1.5
+            p11 = hg * (1 + 0.01 * rng.random(w))
+            rows.append((p11, -0.1 * hg * np.sin(th) ** 2 * rng.random(), p11 * (1 - 0.01 * rng.random(w)), hg * xmu * rng.random()))
+        stack = [np.array([r[k] for r in rows]) for k in range(4)]
+        for itr in (0, 1):
+            many = A.decompo_legendre_many(itr, xmu, xhr, osnb, *stack)
+            kept = 0
+            for b, r in enumerate(rows):
+                one = A.decompo_legendre(itr, xmu, xhr, osnb, *r)
+                for k in one:
+                    assert np.array_equal(np.asarray(one[k]), np.asarray(many[b][k])), (nbm, itr, b, k)
+                kept += one["itronc"]
+            assert (kept > 0) == bool(itr) and kept < len(rows)
