@@ -1451,7 +1451,8 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 # The chunk goes to the solver in a few parts: the solves of a part run on the device while the host prepares the
                 # next one, so that only the last part's solve is waited for below.
                 solved = []                       # (plans, rec [nw][S][3][W], scal [nw][10+N]) device tensors
-                nsub = max(1, min(int(parts), len(idx) // 32))    # (at least 32 wavelengths per part: a launch per kernel variant each)
+                # (at least 32 wavelengths per part -- a launch per kernel variant each; SOS_SPECTRUM_MIN_PART: the tests' override)
+                nsub = max(1, min(int(parts), len(idx) // max(1, int(os.environ.get("SOS_SPECTRUM_MIN_PART", "32")))))
                 step = max(1, -(-len(idx) // nsub))
                 for s0 in range(0, len(idx), step):
                     part = []

@@ -142,6 +142,12 @@ def test_sos_spectrum_equals_sequential_sos_proc_bitwise(gpu_pkg, tmp_path, monk
     for a, b in zip(outs[:12], outs2):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y))
+    # ... and so does handing a chunk to the solver in parts (the solves of a part overlap the preparation of the next)
+    monkeypatch.setenv("SOS_SPECTRUM_MIN_PART", "4")
+    outs3 = rs.sos_spectrum(kws, parts=3, prep_streams=5)
+    for a, b in zip(outs, outs3):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
 @pytest.mark.gpu
