@@ -849,6 +849,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "proc_aer":
         gen_sos_proc_aer(sys.argv[2:])
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "proc_random" and sys.argv[2] == "more":
+        gen_sos_proc_random(12, seed=777, gas=False, first=20)      # round 3: sos_proc_rand_20..31 (no gas), 32..39 (CKD bands)
+        gen_sos_proc_random(8, seed=778, gas=True, first=32)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proc_random":
         if len(sys.argv) > 3 and sys.argv[3] == "gas":
             gen_sos_proc_random(int(sys.argv[2]), seed=7, gas=True, first=12)

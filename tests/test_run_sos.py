@@ -252,7 +252,7 @@ RANDOM_CASES = sorted(f[len("sos_proc_"):-4] for f in os.listdir(GOLD) if f.star
 @pytest.mark.parametrize("name", RANDOM_CASES)
 def test_sos_proc_random_keyword_sets_vs_reference(gpu_pkg, name, tmp_path, monkeypatch):
     """Fuzz at the drop-in boundary: seeded random keyword sets (surfaces 0-5 and 7, exponential and layer aerosol profiles,
-    scalar and polarised runs, IGMAX limits, output altitudes, user viewing angles, fixed-azimuth and polar views; rand_12..19:
+    scalar and polarised runs, IGMAX limits, output altitudes, user viewing angles, fixed-azimuth and polar views; rand_12..19, 32..39:
     multi-bin CKD bands with random atmospheres, gas amounts and both CKD modes) through the
     compiled reference's SOS_PROC (make_golden.py proc_random) and through run_sos.sos_proc on the GPU.  Aerosols enter through
     the reference's own Aerosols.txt (-AER.UserFile), so the comparison is at 1e-9 (2e-7 over land: REAL*4 surface matrices)."""
