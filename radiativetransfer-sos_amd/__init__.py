@@ -12,7 +12,7 @@ __all__ = ["synth", "capi", "solver", "build_ext", "SosContext"]
 
 def __getattr__(name):
     import importlib
-    if name in ("capi", "solver", "build_ext", "run_sos", "dist", "surface", "ckd", "absorption", "aerosols"):
+    if name in ("capi", "solver", "build_ext", "run_sos", "dist", "surface", "ckd", "absorption", "aerosols", "spectrum_pool"):
         return importlib.import_module("." + name, __name__)
     if name in ("SosContext", "SosBinError"):
         return getattr(importlib.import_module(".solver", __name__), name)

@@ -197,3 +197,30 @@ def test_sos_spectrum_wavelengths_over_ranks_on_one_gpu(tmp_path, world):
     assert r["world"] == world and len(set(r["digests"])) == 1, r["digests"]
     assert sorted(i for own in r["owners"] for i in own) == list(range(r["n"]))
     assert all(len(own) > 0 for own in r["owners"])
+
+
+@pytest.mark.gpu
+def test_spectrum_pool_of_host_processes_equals_sos_spectrum(gpu_pkg, tmp_path, monkeypatch):
+    """spectrum_pool.SpectrumPool: two worker processes on the same GPU take the wavelengths of a spectrum by cost; the 23-tuples
+    that come back equal run_sos.sos_spectrum's in this process bit for bit, a second run on the same pool too, and a refused
+    call raises SosProcError in the caller."""
+    rs, sp = gpu_pkg.run_sos, gpu_pkg.spectrum_pool
+    monkeypatch.setenv("SOS_ABS_ROOT", GOLD)
+    kws, golds, coefs, rtols = spectrum_cases.build(rs, tmp_path)
+    kws = kws[:30]
+    ref = rs.sos_spectrum(kws)
+    with sp.SpectrumPool(processes=2) as pool:
+        for _ in range(2):
+            outs = pool.run(kws)
+            assert len(outs) == len(kws)
+            for a, b in zip(ref, outs):
+                for x, y in zip(a, b):
+                    assert np.array_equal(np.asarray(x), np.asarray(y))
+        bad = dict(kws[3])
+        bad["tetas"] = 95.0
+        with pytest.raises(rs.SosProcError):
+            pool.run(kws[:3] + [bad] + kws[4:8])
+        outs = pool.run(kws[:5])                             # the pool survives a refused spectrum
+        for a, b in zip(ref[:5], outs):
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
