@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--streams", type=int, default=16, help="side streams of sos_spectrum (prep_streams)")
+    ap.add_argument("--pool", type=int, default=0, help="also run the spectrum through spectrum_pool with this many host processes")
     a = ap.parse_args()
     import torch
     pkg = importlib.import_module("radiativetransfer-sos_amd")
@@ -77,10 +78,24 @@ def main():
         rs.PREPARE_SEGMENTS.clear()
     tm = {}
     t0 = time.perf_counter()
-    rs.sos_spectrum(kws, timings=tm, chunk=a.chunk, prep_streams=a.streams)
+    full = rs.sos_spectrum(kws, timings=tm, chunk=a.chunk, prep_streams=a.streams)
     dt = time.perf_counter() - t0
     print("(c) sos_spectrum, FULL      : %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s, %8.1f bins/s" % (len(kws), nb, dt, len(kws) / dt, nb / dt))
     print("    host phases per wavelength (ms): " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in tm.items()), flush=True)
+    if a.pool:
+        sp = pkg.spectrum_pool
+        t0 = time.perf_counter()
+        pool = sp.SpectrumPool(processes=a.pool)
+        t1 = time.perf_counter()
+        pool.run(kws[::8])                                   # warm-up of the workers: table parsing, Mie records, surface matrices
+        t2 = time.perf_counter()
+        outs = pool.run(kws)
+        dt = time.perf_counter() - t2
+        print("(d) spectrum_pool, %d processes: %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s, %8.1f bins/s   (pool start %.1f s, "
+              "warm-up run %.1f s)" % (a.pool, len(kws), nb, dt, len(kws) / dt, nb / dt, t1 - t0, t2 - t1), flush=True)
+        same = all(np.array_equal(np.asarray(x), np.asarray(y)) for s1, s2 in zip(full, outs) for x, y in zip(s1, s2))
+        print("    outputs identical to sos_spectrum in this process, bit for bit: %s" % same, flush=True)
+        pool.close()
     if rs.PREPARE_SEGMENTS:                                  # SOS_PREPARE_SEGMENTS=1: where the preparation spends its host time
         print("    prepare, by segment (ms)       : " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in rs.PREPARE_SEGMENTS.items()),
               flush=True)
