@@ -42,7 +42,25 @@ def main():
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--streams", type=int, default=16, help="side streams of sos_spectrum (prep_streams)")
     ap.add_argument("--pool", type=int, default=0, help="also run the spectrum through spectrum_pool with this many host processes")
+    ap.add_argument("--pool-only", action="store_true", help="only the spectrum_pool run: this process never touches the GPU")
     a = ap.parse_args()
+    if a.pool_only:
+        pkg = importlib.import_module("radiativetransfer-sos_amd")
+        rs, sp = pkg.run_sos, pkg.spectrum_pool
+        root = tempfile.mkdtemp(prefix="synth_fic_")
+        synth_ckd.write_tables(root)
+        os.environ["SOS_ABS_ROOT"] = root
+        kws = spectrum_kwargs(rs, a.every)
+        nb = sum(pkg.absorption.band_bin_count(kw["wa_simu"], 10.0) for kw in kws)
+        with sp.SpectrumPool(processes=a.pool or 4) as pool:
+            pool.run(kws[::8])
+            for _ in range(2):
+                t0 = time.perf_counter()
+                pool.run(kws)
+                dt = time.perf_counter() - t0
+                print("(d) spectrum_pool alone, %d processes: %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s" % (
+                    a.pool or 4, len(kws), nb, dt, len(kws) / dt), flush=True)
+        return
     import torch
     pkg = importlib.import_module("radiativetransfer-sos_amd")
     rs = pkg.run_sos
