@@ -12,6 +12,11 @@ run_sos.sos_spectrum returns for that call, bit for bit (the workers run exactly
     pool.close()
 or  outs = sos_spectrum_processes(kwargs_list, processes=4)      # a module-level pool, kept for the next call
 
+Measured (scripts/hyperspectral_bench.py --pool 4, 2496 wavelengths of BASELINE config 5): 2105 wavelengths/s from a caller
+that does not use the GPU itself, against 1450-1500 for sos_spectrum in one process.  The caller's own HIP context counts
+towards the card's queues: from a process that has already run GPU work on 16 hardware queues (GPU_MAX_HW_QUEUES=16) the
+same pool gives 1500 -- start such a caller with a small GPU_MAX_HW_QUEUES, or let the pool do all the GPU work.
+
 The workers are plain child processes speaking length-prefixed pickles over their stdin / stdout (no multiprocessing start
 method, so nothing is re-imported from the caller's __main__).  Under `torchrun` use run_sos.sos_spectrum itself: the ranks
 are the processes.  Result files of a call (-SOS_Main.ResRoot) are written by the worker that owns it.
