@@ -479,29 +479,45 @@ void launch_profile(const ProfileArgs &a, hipStream_t st)
 // depends on the gas, on the exponential term chosen for it and on the layer only, so the host tabulates
 // xk[gas][term][layer] (COEFF_ABS_CKD, SOS_SUB_TRS.F:171) once and a bin is one term index per gas.  Per bin, exactly the
 // reference's loop: layer optical depth = sum over the eight gases (in order) of XK RO, transmission accumulated from the
-// top, TAUABS(level) = -ln(TRS) or CTE_TAUABS_MAX when the transmission underflows.  One thread per bin.
+// top, TAUABS(level) = -ln(TRS) or CTE_TAUABS_MAX when the transmission underflows.
 // ---------------------------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-__global__ void k_absprofile(int nb, int nlev, int nterm, const int32_t *__restrict__ ik, const double *__restrict__ xk,
-                             const double *__restrict__ ro, double *__restrict__ tabs)
+// One WAVEFRONT per bin (round 3; one thread per bin before: 49 dependent exp / log pairs, 80 us for a band -- a sixth of the
+// device-side chain of a wavelength in sos_spectrum).  Lane j forms the optical depth of layer j (the eight gases added in the
+// reference's order) and its transmission; the running product TRS is then formed in layer order -- the same left-to-right
+// product as the loop's -- each lane keeping the value of its own layer, and takes its logarithm.  Bands with more layers than
+// lanes walk the layers in blocks of 64 with the product carried over.
+__global__ __launch_bounds__(64) void k_absprofile(int nb, int nlev, int nterm, const int32_t *__restrict__ ik,
+                                                   const double *__restrict__ xk, const double *__restrict__ ro,
+                                                   double *__restrict__ tabs)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
     const int nl1 = nlev - 1;
     int term[8];
     for (int k = 0; k < 8; k++) term[k] = min(max(ik[8 * b + k], 1), nterm) - 1;
-    double trs = 1.0;
-    tabs[(size_t)b * nlev] = 0.;
-    for (int j = 0; j < nl1; j++) {
-        double t1c = 0.;
-        for (int k = 0; k < 8; k++) t1c = t1c + xk[((size_t)k * nterm + term[k]) * nl1 + j] * ro[(size_t)k * nl1 + j];
-        trs = trs * exp(-t1c);
-        tabs[(size_t)b * nlev + j + 1] = (trs > 0.) ? -log(trs) : 999.;            // CTE_TAUABS_MAX (SOS.h:297)
+    if (lane == 0) tabs[(size_t)b * nlev] = 0.;
+    double trs = 1.0;                                            // TRS after the layers of the blocks before (wave-uniform)
+    for (int j0 = 0; j0 < nl1; j0 += 64) {
+        const int j = j0 + lane;
+        double e = 1.0;
+        if (j < nl1) {
+            double t1c = 0.;
+            for (int k = 0; k < 8; k++) t1c = t1c + xk[((size_t)k * nterm + term[k]) * nl1 + j] * ro[(size_t)k * nl1 + j];
+            e = exp(-t1c);
+        }
+        double mine = 0.;
+        const int cnt = min(64, nl1 - j0);
+        for (int q = 0; q < cnt; q++) {                          // TRS = TRS * EXP(-T1C), layer by layer
+            trs = trs * lane_read(e, q);
+            if (q == lane) mine = trs;
+        }
+        if (j < nl1) tabs[(size_t)b * nlev + j + 1] = (mine > 0.) ? -log(mine) : 999.;           // CTE_TAUABS_MAX (SOS.h:297)
     }
 }
 
 void launch_absprofile(int nb, int nlev, int nterm, const int32_t *d_ik, const double *d_xk, const double *d_ro, double *d_tabs,
                        hipStream_t st)
 {
-    k_absprofile<<<(nb + 63) / 64, 64, 0, st>>>(nb, nlev, nterm, d_ik, d_xk, d_ro, d_tabs);
+    k_absprofile<<<nb, 64, 0, st>>>(nb, nlev, nterm, d_ik, d_xk, d_ro, d_tabs);
 }
