@@ -828,12 +828,21 @@ def _aerosols_at_waref(p, nb_mie, os_nb, device):
     return out
 
 
-def _gas_table_request(kw):
-    """The arguments of the SOS_PREPA_ABSPROFILE call _prepare(kw) will make (absorption.prefetch_gas_tables), or None when the
-    call has no gas absorption or its parameters are refused (the real pass reports)."""
+def _validated(kw):
+    """The keyword set as _prepare sees it after the parameter checks (a copy with their side effects), or None when they refuse it."""
     try:
         p = dict(kw)
         validate_parameters(p)
+        return p
+    except Exception:
+        return None
+
+
+def _gas_table_request(p):
+    """The arguments of the SOS_PREPA_ABSPROFILE call _prepare will make for the validated keyword set p
+    (absorption.prefetch_gas_tables), or None when the call has no gas absorption or its parameters are refused (the real pass
+    reports)."""
+    try:
         absprofil = int(p["absprofil"])
         if absprofil == _I or not 0 <= absprofil <= 6 or p["nustep"] == _I or p["wa_simu"] == _D:
             return None
@@ -843,12 +852,10 @@ def _gas_table_request(kw):
         return None
 
 
-def _aerosol_call(kw, aer_phase):
-    """(p, nb_mie, os_nb) of the SOS_AEROSOLS run _prepare(kw, aer_phase) will make at the simulation wavelength, or None when
-    that step does not run or its parameters are refused (the real pass reports)."""
+def _aerosol_call(p, aer_phase):
+    """(p, nb_mie, os_nb) of the SOS_AEROSOLS run _prepare will make at the simulation wavelength for the validated keyword set p,
+    or None when that step does not run or its parameters are refused (the real pass reports)."""
     try:
-        p = dict(kw)
-        validate_parameters(p)
         if (p["aot_ref"] in (0.0, _D) or aer_phase is not None or str(p["ficuser_aer"]).strip() != "NO_USER_AEROSOLS"
                 or p["waref_aot"] == _D or p["wa_simu"] in (_D, p["waref_aot"]) or p["imod_aer"] not in (0, 1, 2, 3, 4, 5)):
             return None
@@ -1425,7 +1432,8 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                 for st in side + [aer_st]:
                     st.wait_stream(main_st)
                 # the size-distribution integrals of the chunk's wavelengths, queued ahead (aerosols.prefetch_size_integrals)
-                acalls = {i: c for i, c in ((i, _aerosol_call(kwargs_list[i], aer_phases[i])) for i in idx) if c is not None}
+                valid = {i: v for i, v in ((i, _validated(kwargs_list[i])) for i in idx) if v is not None}
+                acalls = {i: c for i, c in ((i, _aerosol_call(v, aer_phases[i])) for i, v in valid.items()) if c is not None}
                 reqs = []
                 for c in acalls.values():
                     reqs += _size_integral_requests(c, device)
@@ -1433,7 +1441,7 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
                     with torch.cuda.stream(aer_st):
                         _aer.prefetch_size_integrals(reqs)
                 # ... and the gas tables of the chunk's wavelengths, interpolated to the layers in one pass
-                greqs = [r for r in (_gas_table_request(kwargs_list[i]) for i in idx) if r is not None]
+                greqs = [r for r in (_gas_table_request(v) for v in valid.values()) if r is not None]
                 if greqs:
                     _abs.prefetch_gas_tables(greqs)
                 # ... and SOS_AEROSOLS at the simulation wavelength of each, the Legendre expansions formed together (the gas tables

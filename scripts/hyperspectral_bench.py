@@ -100,6 +100,13 @@ def main():
     dt = time.perf_counter() - t0
     print("(c) sos_spectrum, FULL      : %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s, %8.1f bins/s" % (len(kws), nb, dt, len(kws) / dt, nb / dt))
     print("    host phases per wavelength (ms): " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in tm.items()), flush=True)
+    tm2 = {}
+    t0 = time.perf_counter()
+    rs.sos_spectrum(kws, timings=tm2, chunk=a.chunk, prep_streams=a.streams)
+    dt2 = time.perf_counter() - t0
+    print("(c) sos_spectrum, FULL again: %4d wavelengths (%d bins) in %6.2f s = %7.1f wavelengths/s   (every table file parsed by now)" % (
+        len(kws), nb, dt2, len(kws) / dt2))
+    print("    host phases per wavelength (ms): " + ", ".join("%s %.3f" % (k, 1e3 * v / len(kws)) for k, v in tm2.items()), flush=True)
     if a.pool:
         sp = pkg.spectrum_pool
         t0 = time.perf_counter()
