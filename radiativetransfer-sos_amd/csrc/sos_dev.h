@@ -546,13 +546,13 @@ __device__ __forceinline__ void combine_shared(double *cbuf, int t, int nth, int
 template <int NW, int FS, int KHM, int LEVELS>
 __device__ __forceinline__ void combine_field(double *fld, int lane, int wv)
 {
-    static_assert(KHM == 128 || KHM == 64 || KHM == 256, "rows per half");
+    static_assert(KHM % 16 == 0, "rows per half");
 #pragma unroll
     for (int l = 0; l < LEVELS / NW; l++) {
         double *row = fld + (size_t)(wv + l * NW) * FS;
 #pragma unroll
         for (int r = 0; r < KHM; r += 128) {
-            if (KHM >= 128 || lane < KHM / 2) {
+            if (KHM - r >= 128 || 2 * lane < KHM - r) {
                 v2d *pp = reinterpret_cast<v2d *>(row + r + 2 * lane), *pm = reinterpret_cast<v2d *>(row + KHM + r + 2 * lane);
                 const v2d xp = *pp, xm = *pm;
                 *pp = xp + xm; *pm = xp - xm;
