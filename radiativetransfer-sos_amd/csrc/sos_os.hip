@@ -57,22 +57,22 @@
 // The one-row-tile variants of up to 32 levels (N <= 21: 41 KB of LDS per workgroup) run THREE workgroups per CU (round 3): 168
 // registers per lane instead of 256 cost 19-61 spilled registers, the third wave per SIMD hides more of the formal solution's
 // latency than that costs -- N = 13 / 17 / 21 at NT = 30: 700 / 602 / 482 -> 820 / 687 / 541 k bins/s (profiles/r03_n_sweep.txt).
-// KHT = row tiles per half of the field LAYOUT (sos_stream.hip skhm/sfs/sns have the same meaning): NW RTWH by default; 5 for the
-// five-tile layout of N = 22 ... 26 (51 KB of LDS per workgroup instead of 80: three workgroups per CU as well).
+// (The same for N = 22 ... 26 -- a five-tile field layout as in sos_stream.hip, 51 KB per workgroup, three workgroups per CU, wave 0
+// carrying the fifth tile -- was built and measured against the shared-tile form on two workgroups: 375.7 vs 371.1 k bins/s at
+// N = 25, 335.1 vs 336.5 at N = 26, with 132-185 spilled registers; a wash, not kept.)
 #ifdef SOS_NO_3WG
-#define SOS_MIN_WG_R(NW, RTWH, CT, KHT) SOS_MIN_WG(NW, CT)
+#define SOS_MIN_WG_R(NW, RTWH, CT) SOS_MIN_WG(NW, CT)
 #else
-#define SOS_MIN_WG_R(NW, RTWH, CT, KHT) (((NW) == 4 && (CT) == 2 && ((RTWH) == 1 || (KHT) == 5)) ? 3 : SOS_MIN_WG(NW, CT))
+#define SOS_MIN_WG_R(NW, RTWH, CT) (((NW) == 4 && (RTWH) == 1 && (CT) == 2) ? 3 : SOS_MIN_WG(NW, CT))
 #endif
-template <int NW, int RTWH, int CT, bool ZO, bool SURF, bool SPLIT, int KHT = NW * RTWH>
-__global__ __launch_bounds__(64 * NW, SOS_MIN_WG_R(NW, RTWH, CT, KHT)) void k_sos_os(const SosDev cx_arg, const SosBins bn)
+template <int NW, int RTWH, int CT, bool ZO, bool SURF, bool SPLIT>
+__global__ __launch_bounds__(64 * NW, SOS_MIN_WG_R(NW, RTWH, CT)) void k_sos_os(const SosDev cx_arg, const SosBins bn)
 {
     SOS_BIND_CTX(cx, cx_arg, bn);
     extern __shared__ double smem[];
     constexpr int NTH = 64 * NW, HW = NW / 2;
     constexpr int COLS = 16 * CT;
-    static_assert(KHT > NW * (RTWH - 1) && KHT <= NW * RTWH && (!SPLIT || KHT == NW * RTWH), "layout rows; the shared-tile form needs the pad rows");
-    constexpr int KHM = 16 * KHT, FS = 2 * KHM + 2, NS = (KHM / 3 + 1) & ~1;
+    constexpr int KHM = sos_khm(NW, RTWH), FS = sos_fs(NW, RTWH), NS = sos_ns(NW, RTWH);
     const int N = cx.n, KP = cx.kp, KH = cx.kh, W = cx.w;
     constexpr int LPB = COLS;              // level capacity of the field storage
     double *cbuf = smem;                   // [COLS][FS]  LDS: the field itself
@@ -497,25 +497,13 @@ static bool sos_split_applies(const SosDev &cx, int nw, int rtw, int ct)
 #endif
 }
 
-// LDS of a variant whose field layout has kht row tiles per half (the five-tile layout; lds_bytes_for with its own FS, NS)
-static size_t lds_bytes_kht(int kht, int ct)
-{
-    const int cols = 16 * ct, khm = 16 * kht, fs = 2 * khm + 2, ns = (khm / 3 + 1) & ~1;
-    return ((size_t)cols * fs + 3 * ns + 2 + 2 * ns + 16 + 2 * ns + (size_t)cols * ns + 7 * cols) * sizeof(double);
-}
-
-template <int NW, int RTWH, int CT, bool ZO, bool SURF, bool SPLIT = false, int KHT = NW * RTWH>
+template <int NW, int RTWH, int CT, bool ZO, bool SURF, bool SPLIT = false>
 static int launch_variant(const SosDev &cx, const SosBins &bn, size_t lds, hipStream_t st, int *hip_err)
 {
-    if constexpr (!SPLIT && NW == 4 && RTWH == 2 && CT == 2 && KHT == NW * RTWH) {
-        // five row tiles (N = 22 ... 26): SOSGPU_OS_NARROW=1 -- the five-tile layout, three workgroups per CU, wave 0 carrying
-        // the fifth tile; default -- the full-width layout with the shared-tile contraction, two workgroups per CU
-        static const int narrow = [] { const char *e = getenv("SOSGPU_OS_NARROW"); return e ? atoi(e) : 0; }();
-        if (narrow && cx.kh <= 80 && cx.rtph == 5)
-            return launch_variant<NW, RTWH, CT, ZO, SURF, false, 5>(cx, bn, lds_bytes_kht(5, CT), st, hip_err);
+    if constexpr (!SPLIT && NW == 4 && RTWH == 2 && CT == 2) {
         if (sos_split_applies(cx, NW, RTWH, CT)) return launch_variant<NW, RTWH, CT, ZO, SURF, true>(cx, bn, lds, st, hip_err);
     }
-    auto kern = k_sos_os<NW, RTWH, CT, ZO, SURF, SPLIT, KHT>;
+    auto kern = k_sos_os<NW, RTWH, CT, ZO, SURF, SPLIT>;
 #ifdef SOS_PROFILE_PHASES
     if (const char *e = getenv("SOSGPU_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);   // diagnostic builds: force 1 workgroup per CU
 #endif

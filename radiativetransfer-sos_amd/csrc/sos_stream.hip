@@ -133,10 +133,10 @@ __device__ __forceinline__ void glds_copy(const double *g, double *l, int units,
 
 // Workgroups per CU.  The four-tile layout (N <= 21: 42 KB of LDS per workgroup) runs THREE (round 3): 168 instead of 256
 // registers per lane, and the third wave per SIMD hides more latency than the spills cost -- N = 13 / 17 / 21 at NT = 120:
-// 103 / 93 / 81 -> 114 / 103 / 87 k bins/s (profiles/r03_n_sweep.txt).  SOS_STREAM_3WG_KHT: the widest layout that does (4;
-// 5 = experiment: 52 KB per workgroup still fits three).
+// 103 / 93 / 81 -> 114 / 103 / 87 k bins/s -- and so does the five-tile layout (N <= 26: 52 KB): N = 25 60.1 -> 65.4 k bins/s
+// (profiles/r03_n_sweep.txt).  SOS_STREAM_3WG_KHT: the widest layout that does.
 #ifndef SOS_STREAM_3WG_KHT
-#define SOS_STREAM_3WG_KHT 4
+#define SOS_STREAM_3WG_KHT 5
 #endif
 #define SOS_STREAM_MIN_WG(NW, KHT) ((NW) == 4 ? ((COLS == 16 || (KHT) <= SOS_STREAM_3WG_KHT) ? 3 : 2) : 1)
 template <int NW, int RTWH, bool ZO, bool SURF, bool PERSIST, int KHT = NW * RTWH>
