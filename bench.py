@@ -418,10 +418,11 @@ def measure_headline(pkg, S, torch, dist, world, rank, dev, nbins, steps, warmup
     return res, wl, nord
 
 
-def measure_variant(pkg, S, torch, name, nbins, kw, nt=30, g=0.75):
-    """The headline workload with another surface (BASELINE configs 3 and 4: the SURF / Fresnel variants of k_sos_os), kernel
-    time from HIP events, executed-flops roofline fraction."""
-    mu, w, n0 = S.gauss_angles(40, 35.0)
+def measure_variant(pkg, S, torch, name, nbins, kw, nt=30, g=0.75, ng=40):
+    """The headline workload with another surface (BASELINE configs 3 and 4: the SURF / Fresnel variants of k_sos_os), another
+    number of Gauss angles or levels (the reference's default of 24 angles: other kernel instantiations), kernel time from HIP
+    events, executed-flops roofline fraction."""
+    mu, w, n0 = S.gauss_angles(ng, 35.0)
     os_nb = 80
     al, be, ga, ze = S.hg_phase(os_nb, g)
     b = S.ckd_bins(nbins, nt, seed=1234)
@@ -619,7 +620,13 @@ def main():
         res["variants"] = [measure_variant(pkg, S, torch, "cfg3 flat sea (Fresnel interface, n = 1.34)", SMALL_BATCH,
                                            dict(ro=0.02, ifresnel=1, ind_surf=1.34)),
                            measure_variant(pkg, S, torch, "cfg4 Cox-Munk glitter 7 m/s (surface matrices, ground_mfma)", SMALL_BATCH,
-                                           dict(ro=0.0, imat_surf=1))]
+                                           dict(ro=0.0, imat_surf=1)),
+                           # the reference's default angle count (24 Gauss angles, N = 25): the shared-tile LDS variant and the
+                           # five-tile layout of the streamed kernel
+                           measure_variant(pkg, S, torch, "N = 25 (24 Gauss angles), NT = 30: k_sos_os<4,2,2,split>", SMALL_BATCH,
+                                           dict(ro=0.1), ng=24),
+                           measure_variant(pkg, S, torch, "N = 25 (24 Gauss angles), NT = 120: k_sos_stream<4,2,KHT=5>", SMALL_BATCH,
+                                           dict(ro=0.1), nt=120, ng=24)]
         if not args.no_hyper:
             res["hyperspectral"] = run_hyperspectral(pkg, torch, dist, world, rank, args.spectrum_every)
             if hyper_procs4:
