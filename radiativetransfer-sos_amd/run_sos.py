@@ -283,6 +283,7 @@ def write_mie_angles(path, nb_gauss, os_nb, user_file="NO_USER_ANGLES"):
 # host-side restatements of the steps before the hot path (inputs of SOS_OS)
 # ---------------------------------------------------------------------------------------------------------
 _ANGLES_CACHE = collections.OrderedDict()
+_ANGLES_LOCK = threading.Lock()
 
 
 def angles(nbmu_gauss, tetas, user_file="NO_USER_ANGLES"):
@@ -298,13 +299,15 @@ def angles(nbmu_gauss, tetas, user_file="NO_USER_ANGLES"):
             key += (st.st_size, st.st_mtime_ns)
         except OSError:
             key = None
-    hit = _ANGLES_CACHE.get(key) if key is not None else None
+    with _ANGLES_LOCK:
+        hit = _ANGLES_CACHE.get(key) if key is not None else None
     if hit is None:
         hit = _angles(nbmu_gauss, tetas, user_file)
         if key is not None:
-            _ANGLES_CACHE[key] = hit
-            while len(_ANGLES_CACHE) > 16:
-                _ANGLES_CACHE.popitem(last=False)
+            with _ANGLES_LOCK:
+                _ANGLES_CACHE[key] = hit
+                while len(_ANGLES_CACHE) > 16:
+                    _ANGLES_CACHE.popitem(last=False)
     mu, ga, n0, ind = hit
     return mu.copy(), ga.copy(), n0, ind.copy()
 
