@@ -1416,6 +1416,13 @@ def sos_spectrum(kwargs_list, aer_phases=None, device=0, gather=True, chunk=256,
     main_st = torch.cuda.current_stream(dev)
     side = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(prep_streams)))]
     aer_st = torch.cuda.Stream(device=dev)
+    if len(mine) >= 64 and "GPU_MAX_HW_QUEUES" not in os.environ and not getattr(sos_spectrum, "_warned_queues", False):
+        import warnings
+        sos_spectrum._warned_queues = True
+        warnings.warn("GPU_MAX_HW_QUEUES is not set: the HIP runtime maps the %d preparation streams of sos_spectrum onto 4 hardware "
+                      "queues and the device side of the preparation becomes the limit (about 2/3 of the throughput); export "
+                      "GPU_MAX_HW_QUEUES=16 before the first GPU call of the process (16 // processes when several processes share "
+                      "the GPU)" % len(side), RuntimeWarning, stacklevel=2)
     # The cyclic garbage collector is paused for the pass: a spectrum allocates tens of container objects per wavelength next to
     # a growing list of result tuples, and the collections this triggers re-walk the results again and again (SOS_SPECTRUM_KEEP_GC=1
     # leaves the collector alone).  Nothing here relies on it: contexts are closed explicitly, tensors are freed by reference count.
